@@ -1,0 +1,47 @@
+import json
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+REPO = Path(__file__).resolve().parent.parent
+GOLDEN = REPO / "tests" / "golden"
+if str(REPO) not in sys.path:
+    sys.path.insert(0, str(REPO))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name: str):
+    """-> (dict of tensors, meta dict) from tests/golden/<name>.safetensors."""
+    from safetensors import safe_open
+    f = safe_open(str(GOLDEN / f"{name}.safetensors"), "pt")
+    tensors = {k: f.get_tensor(k) for k in f.keys()}
+    meta = json.loads(f.metadata().get("meta", "{}"))
+    return tensors, meta
+
+
+def bf16_ulp(x: torch.Tensor) -> torch.Tensor:
+    """Spacing of bf16 numbers at |x| (8 significant bits)."""
+    a = x.float().abs().clamp_min(2.0 ** -126)
+    return torch.exp2(torch.floor(torch.log2(a)) - 7)
+
+
+def ulp_diff(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """|a-b| in units of the bf16 ulp at max(|a|,|b|)."""
+    a, b = a.float(), b.float()
+    return (a - b).abs() / bf16_ulp(torch.maximum(a.abs(), b.abs()))
+
+
+@pytest.fixture(scope="session")
+def golden():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = load_golden(name)
+        return cache[name]
+    return get

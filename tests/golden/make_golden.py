@@ -1,0 +1,346 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE ITSELF.
+
+Run in the build container only (needs /root/reference; the GPU box never has it):
+
+    python tests/golden/make_golden.py [--skip-full]
+
+It imports the reference's own `ger.lora.GPT`, `generate.base.generate`,
+`ger.utils.chunked_cross_entropy` and `data.prompts` (read-only, from /root/reference) after
+pre-seeding `sys.modules` with empty stand-ins for the third-party packages that are not
+installed here and that the hot path never executes (lightning, lightning_utilities,
+xformers).  The committed outputs are DATA only: inputs, seeds and the tensors
+the reference produced.  Weights are not stored for the big shapes; they are regenerated from
+`dualhyp_amd.synth` (a counter-based hash, bit-stable across machines and devices).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import sys
+import types
+from pathlib import Path
+
+import torch
+import torch.nn as nn
+
+HERE = Path(__file__).resolve().parent
+REPO = HERE.parent.parent
+REF = Path("/root/reference")
+sys.path.insert(0, str(REPO))
+
+
+def _install_stubs() -> None:
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        m.__path__ = []  # behave as a package
+        sys.modules[name] = m
+        return m
+
+    class RequirementCache:  # flash-attn probe must be falsy, everything else truthy
+        def __init__(self, req: str = "", *a, **k):
+            self.req = req
+
+        def __bool__(self):
+            return "flash" not in self.req
+
+    mod("lightning_utilities")
+    mod("lightning_utilities.core")
+    mod("lightning_utilities.core.imports", RequirementCache=RequirementCache)
+    mod("xformers")
+    mod("xformers.ops", SwiGLU=type("SwiGLU", (nn.Module,), {}))
+    L = mod("lightning", Fabric=object)
+    mod("lightning.fabric")
+    mod("lightning.fabric.utilities")
+    mod("lightning.fabric.utilities.load", _lazy_load=None, _NotYetLoadedTensor=object)
+    mod("lightning.fabric.loggers", CSVLogger=object)
+    mod("lightning.fabric.strategies", FSDPStrategy=object)
+    mod("lightning.fabric.wrappers", _FabricModule=object)
+    mod("lightning.fabric.plugins", BitsandbytesPrecision=object)
+    mod("lightning.fabric.accelerators", CUDAAccelerator=object)
+    mod("lightning.pytorch")
+    mod("lightning.pytorch.callbacks", Callback=object)
+    mod("lightning.pytorch.utilities")
+    mod("lightning.pytorch.utilities.rank_zero", rank_zero_only=lambda f: f)
+    L.fabric = sys.modules["lightning.fabric"]
+
+
+def import_reference():
+    _install_stubs()
+    sys.path.insert(0, str(REF))
+    import ger.lora as rlora  # noqa
+    import ger.model as rmodel  # noqa
+    import ger.utils as rutils  # noqa
+    from generate.base import generate as rgenerate  # noqa
+    import data.prompts as rprompts  # noqa
+    return rlora, rmodel, rutils, rgenerate, rprompts
+
+
+def save(name: str, tensors: dict, meta: dict | None = None) -> None:
+    from safetensors.torch import save_file
+    t = {k: v.detach().contiguous().cpu() for k, v in tensors.items()}
+    md = {"meta": json.dumps(meta or {})}
+    save_file(t, str(HERE / f"{name}.safetensors"), metadata=md)
+    sz = (HERE / f"{name}.safetensors").stat().st_size
+    print(f"wrote {name}.safetensors ({sz/1024:.0f} KiB)")
+
+
+def ref_model(rlora, cfg_kwargs: dict, sd: dict, dtype):
+    cfg = rlora.Config(**cfg_kwargs)
+    with torch.device("cpu"):
+        m = rlora.GPT(cfg)
+    m = m.to(dtype)
+    missing, unexpected = m.load_state_dict({k: v.to(dtype) for k, v in sd.items()}, strict=True)
+    m.eval()
+    return m
+
+
+def cfg_kwargs_of(cfg) -> dict:
+    d = cfg.to_dict()
+    d.pop("rope_n_elem", None)
+    return d
+
+
+def top2_margin_ulps(logits: torch.Tensor) -> float:
+    """(top1-top2) in units of the bf16 ulp at top1 (0 => exact tie)."""
+    v, _ = torch.topk(logits.float(), 2)
+    e = math.floor(math.log2(abs(v[0].item()))) if v[0].item() != 0 else -126
+    return (v[0] - v[1]).item() / 2.0 ** (e - 7)
+
+
+# ------------------------------------------------------------------------------------------
+def gen_tiny(rlora, rutils, rgenerate, name: str, cfg_name: str, r: int, seed: int) -> None:
+    """Tiny model end to end: forward (no cache), prefill + decode steps with the KV cache,
+    generate(), chunked CE loss + LoRA grads of one training micro-step, merged-LoRA logits.
+    fp32 and bf16 runs share the same (bf16-valued) weights."""
+    from dualhyp_amd.config import Config
+    from dualhyp_amd.synth import synth_state_dict, synth_prompts
+
+    cfg = Config.from_name(cfg_name, r=r, alpha=2 * r, dropout=0.0, to_query=True, to_key=True,
+                           to_value=True, to_projection=True)
+    # larger weights than the 0.02 default so tiny-model logits are not all ~0
+    sd = synth_state_dict(cfg, seed=seed, norm_jitter=0.25, weight_scale=4.0)
+    T, G = 24, 12
+    idx = synth_prompts(2, T, cfg.padded_vocab_size, seed=seed)
+    out = {"idx0": idx[0], "idx1": idx[1]}
+    meta = {"config": cfg_kwargs_of(cfg), "seed": seed, "T": T, "G": G,
+            "norm_jitter": 0.25, "weight_scale": 4.0}
+
+    for tag, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        m = ref_model(rlora, cfg_kwargs_of(cfg), sd, dt)
+        with torch.no_grad():
+            batch = torch.stack(idx)
+            out[f"{tag}.logits_nocache"] = m(batch)                      # (2,T,V)
+            # cache path, batch 1, prefill + 3 decode steps feeding the argmax back
+            m.reset_cache()
+            pos = torch.arange(T)
+            lg = m(idx[0].view(1, -1), pos)
+            out[f"{tag}.logits_prefill"] = lg
+            toks, steps = [], []
+            nxt = int(lg[0, -1].float().argmax())
+            for s in range(3):
+                toks.append(nxt)
+                lg = m(torch.tensor([[nxt]]), torch.tensor([T + s]))
+                steps.append(lg[0, 0])
+                nxt = int(lg[0, 0].float().argmax())
+            out[f"{tag}.decode_tokens"] = torch.tensor(toks)
+            out[f"{tag}.logits_decode"] = torch.stack(steps)
+            m.reset_cache()
+        # generate(): the reference's sampled "greedy" (top_k=1, temperature 0.2; quirk Q6);
+        # record per-step top-2 margins so tests know which steps are tie-free.
+        torch.manual_seed(seed)
+        g = rgenerate(m, idx[1], T + G, temperature=0.2, top_k=1, eos_id=None)
+        out[f"{tag}.generate_ids"] = g
+        m.reset_cache()
+        margins = []
+        with torch.no_grad():
+            pos = torch.arange(T)
+            lg = m(idx[1].view(1, -1), pos)[0, -1]
+            for s in range(G):
+                margins.append(top2_margin_ulps(lg))
+                if s + 1 < G:
+                    lg = m(g[T + s].view(1, 1), torch.tensor([T + s]))[0, 0]
+            m.reset_cache()
+        out[f"{tag}.generate_margins_ulps"] = torch.tensor(margins)
+        # EOS handling (quirk Q7): stop token excluded from the return value
+        eos = int(g[T + 3])
+        torch.manual_seed(seed)
+        ge = rgenerate(m, idx[1], T + G, temperature=0.2, top_k=1, eos_id=eos)
+        out[f"{tag}.generate_eos_ids"] = ge
+        meta[f"{tag}.eos_id"] = eos
+        m.reset_cache()
+
+        # one training micro-step, reference loop semantics finetune/ger.py:278-285
+        m.train()
+        rlora.mark_only_lora_as_trainable(m)
+        labels = torch.stack(idx).clone()
+        labels[:, : T - 9] = -1                                         # prompt masked
+        logits = m(torch.stack(idx), lm_head_chunk_size=8)
+        logits[-1] = logits[-1][..., :-1, :]
+        loss = rutils.chunked_cross_entropy(logits, labels[..., 1:], chunk_size=8)
+        (loss / 32).backward()
+        out[f"{tag}.train_loss"] = loss.detach()
+        out["train_labels"] = labels
+        for n, p in m.named_parameters():
+            if p.requires_grad:
+                out[f"{tag}.grad.{n}"] = p.grad
+        m.zero_grad()
+        m.eval()
+        with torch.no_grad():
+            lg = m(torch.stack(idx))
+            val = rutils.chunked_cross_entropy(lg[..., :-1, :], labels[..., 1:], chunk_size=0)
+            out[f"{tag}.val_loss"] = val
+            rlora.merge_lora_weights(m)
+            out[f"{tag}.logits_merged"] = m(torch.stack(idx))
+            if tag == "fp32" and name == "tiny_r4":
+                out["merged.attn0"] = m.transformer.h[0].attn.attn.linear.weight.data
+                out["merged.proj0"] = m.transformer.h[0].attn.proj.linear.weight.data
+    save(name, out, meta)
+
+
+def gen_block(rlora, rmodel, name: str, cfg_name: str, seed: int, T: int) -> None:
+    """One decoder block at a production shape, bf16: every intermediate, to pin the rounding
+    points (quirk Q10).  Weights regenerated from the seed at test time."""
+    from dualhyp_amd.config import Config, GER_LORA
+    from dualhyp_amd.synth import synth_state_dict, uniform, stream_id
+
+    cfg = Config.from_name(cfg_name, **{**GER_LORA, "dropout": 0.0})
+    sd = synth_state_dict(cfg, seed=seed, norm_jitter=0.25)
+    m = ref_model(rlora, cfg_kwargs_of(cfg), sd, torch.bfloat16)
+    blk = m.transformer.h[0]
+    d = cfg.n_embd
+    x = uniform((1, T, d), 1.5, stream_id(seed, "block_x"))
+    out = {"x": x}
+    with torch.no_grad():
+        cos, sin = rmodel.build_rope_cache(cfg.block_size, cfg.rope_n_elem, torch.bfloat16, "cpu")
+        out["rope_cos_rows"] = cos[[0, 1, 511 % cfg.block_size, cfg.block_size - 1]]
+        out["rope_sin_rows"] = sin[[0, 1, 511 % cfg.block_size, cfg.block_size - 1]]
+        cs = (cos[:T], sin[:T])
+        n1 = blk.norm_1(x)
+        out["norm_1"] = n1
+        qkv = blk.attn.attn(n1)
+        out["qkv"] = qkv
+        # plain linear / lora pieces of qkv for finer pinning
+        out["qkv_pretrained"] = blk.attn.attn.linear(n1)
+        B_, nq, hs = 1, cfg.n_head // cfg.n_query_groups, cfg.head_size
+        v5 = qkv.view(B_, T, cfg.n_query_groups, nq + 2, hs).permute(0, 2, 3, 1, 4)
+        q, k, v = v5.split((nq, 1, 1), dim=2)
+        q = q.reshape(B_, -1, T, hs)
+        k1 = k.reshape(B_, -1, T, hs)
+        out["q_roped"] = rmodel.apply_rope(q, *cs)          # (1, n_head, T, hs)
+        out["k_roped"] = rmodel.apply_rope(k1, *cs)         # (1, n_groups, T, hs)
+        h, _ = blk.attn(n1, cs, cfg.block_size)
+        out["attn_out"] = h
+        # attention before the output projection
+        captured = {}
+        hook = blk.attn.proj.register_forward_pre_hook(lambda mod, a: captured.__setitem__("y", a[0]))
+        blk.attn(n1, cs, cfg.block_size)
+        hook.remove()
+        out["attn_y"] = captured["y"]
+        x1 = x + h
+        out["resid_1"] = x1
+        n2 = blk.norm_2(x1)
+        out["norm_2"] = n2
+        out["mlp_act"] = torch.nn.functional.silu(blk.mlp.fc_1(n2)) * blk.mlp.fc_2(n2)
+        out["mlp_out"] = blk.mlp(n2)
+        xo, _ = blk(x, cs, cfg.block_size)
+        out["block_out"] = xo
+        # same block through the KV-cache path: prefill T-1 then 1 decode token
+        m.reset_cache()
+        kvs = m.build_kv_caches(x, cfg.block_size, cos.size(-1))
+        mask = m.build_mask_cache(x)
+        pos = torch.arange(T - 1)
+        xa, kv = blk(x[:, : T - 1], (cos[pos], sin[pos]), cfg.block_size,
+                     mask.index_select(2, pos), pos, kvs[0])
+        pos1 = torch.tensor([T - 1])
+        xb, kv = blk(x[:, T - 1:], (cos[pos1], sin[pos1]), cfg.block_size,
+                     mask.index_select(2, pos1), pos1, kv)
+        out["block_out_cache_prefill"] = xa
+        out["block_out_cache_decode"] = xb
+    save(name, out, {"config": cfg_kwargs_of(cfg), "seed": seed, "T": T, "norm_jitter": 0.25})
+
+
+def gen_full(rlora, rgenerate, name: str, seed: int, T: int, G: int) -> None:
+    """Full TinyLlama-1.1B shape (22 layers), bf16, random weights from the hash: last-position
+    logits of the prefill, per-step logits, generated ids with tie margins."""
+    from dualhyp_amd.config import Config, GER_LORA
+    from dualhyp_amd.synth import synth_state_dict, synth_prompts
+
+    cfg = Config.from_name("tiny-llama-1.1b-chat", **{**GER_LORA, "dropout": 0.0})
+    sd = synth_state_dict(cfg, seed=seed)
+    m = ref_model(rlora, cfg_kwargs_of(cfg), sd, torch.bfloat16)
+    del sd
+    idx = synth_prompts(1, T, cfg.padded_vocab_size, seed=seed)[0]
+    out = {"idx": idx}
+    torch.manual_seed(seed)
+    g = rgenerate(m, idx, T + G, temperature=0.2, top_k=1, eos_id=None)
+    out["generate_ids"] = g
+    m.reset_cache()
+    margins, step_logits = [], []
+    with torch.no_grad():
+        hs = {}
+        hooks = [m.transformer.h[i].register_forward_hook(
+            lambda mod, a, o, i=i: hs.__setitem__(i, o[0][0, -4:].clone())) for i in (0, 10, 21)]
+        lg = m(idx.view(1, -1), torch.arange(T))[0]
+        for h_ in hooks:
+            h_.remove()
+        for i in (0, 10, 21):
+            out[f"hidden_l{i}_last4"] = hs[i]
+        out["prefill_logits_last4"] = lg[-4:]
+        lg = lg[-1]
+        for s in range(G):
+            margins.append(top2_margin_ulps(lg))
+            step_logits.append(lg)
+            if s + 1 < G:
+                lg = m(g[T + s].view(1, 1), torch.tensor([T + s]))[0, 0]
+        m.reset_cache()
+    out["generate_margins_ulps"] = torch.tensor(margins)
+    out["step_logits"] = torch.stack(step_logits)
+    save(name, out, {"config": cfg_kwargs_of(cfg), "seed": seed, "T": T, "G": G})
+
+
+def gen_misc(rutils, rprompts) -> None:
+    """Host-logic pins: CE normalisations (Q5), LR schedule, accumulation trace (Q3), prompts."""
+    torch.manual_seed(7)
+    logits = torch.randn(2, 37, 50)
+    targets = torch.randint(0, 50, (2, 37))
+    targets[:, :20] = -1
+    chunks = list(logits.split(8, dim=1))
+    res = {
+        "ce_logits": logits, "ce_targets": targets,
+        "ce_list_chunked": rutils.chunked_cross_entropy([c.clone() for c in chunks], targets, chunk_size=8),
+        "ce_list_unchunked": rutils.chunked_cross_entropy([c.clone() for c in chunks], targets, chunk_size=0),
+        "ce_tensor_chunked": rutils.chunked_cross_entropy(logits, targets, chunk_size=16),
+        "ce_tensor_unchunked": rutils.chunked_cross_entropy(logits, targets, chunk_size=0),
+    }
+    save("misc_ce", res)
+    js = {"prompts": {"GER": rprompts.get_prompts_format("GER"),
+                      "DualHyp": rprompts.get_prompts_format("DualHyp"),
+                      "RelPrompt": rprompts.get_prompts_format("RelPrompt")}}
+    (HERE / "prompts.json").write_text(json.dumps(js, indent=1, ensure_ascii=False))
+    print("wrote prompts.json")
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--skip-full", action="store_true")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    torch.set_num_threads(8)
+    rlora, rmodel, rutils, rgenerate, rprompts = import_reference()
+    want = lambda k: (not a.only) or a.only == k
+    if want("misc"):
+        gen_misc(rutils, rprompts)
+    if want("tiny"):
+        gen_tiny(rlora, rutils, rgenerate, "tiny_r4", "parity-tiny", r=4, seed=1337)
+        gen_tiny(rlora, rutils, rgenerate, "tiny_hs128_r16", "parity-hs128", r=16, seed=4242)
+    if want("block"):
+        gen_block(rlora, rmodel, "block_tinyllama", "parity-block", seed=1337, T=16)
+    if want("full") and not a.skip_full:
+        gen_full(rlora, rgenerate, "full_tinyllama", seed=1337, T=48, G=12)
+
+
+if __name__ == "__main__":
+    main()
