@@ -1,0 +1,78 @@
+// Shared device/host helpers for libdualhyp_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/dualhyp_hip.h"
+
+typedef uint16_t bf16_t;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;    // 8 bf16 = 4 VGPRs (MFMA A/B operand)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;   // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4;     // 16x16 MFMA accumulator
+
+// ---- bf16 <-> f32 (round-to-nearest-even, NaN preserving: plain casts, MI355X_MICROARCH
+// "Correctness boundaries") ---------------------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32 (RNE)
+    return __builtin_bit_cast(bf16_t, b);
+}
+// round an fp32 value to the nearest bf16 and return it as fp32: one rounding point of the
+// reference's eager bf16 tensor program
+__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
+
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+// ---- wave64 reductions ------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- async global -> LDS, 16 B per lane; LDS destination = wave-uniform base + lane*16 ----
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// ---- host-side error plumbing -------------------------------------------------------------
+void dh_set_error(const char* fmt, ...);
+
+#define DH_CHECK(cond, ...)                      \
+    do {                                         \
+        if (!(cond)) {                           \
+            dh_set_error(__VA_ARGS__);           \
+            return 1;                            \
+        }                                        \
+    } while (0)
+
+#define DH_HIP(call)                                                                   \
+    do {                                                                               \
+        hipError_t _e = (call);                                                        \
+        if (_e != hipSuccess) {                                                        \
+            dh_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return 2;                                                                  \
+        }                                                                              \
+    } while (0)
+
+#define DH_LAUNCH_CHECK()                                                              \
+    do {                                                                               \
+        hipError_t _e = hipGetLastError();                                             \
+        if (_e != hipSuccess) {                                                        \
+            dh_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+            return 3;                                                                  \
+        }                                                                              \
+    } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

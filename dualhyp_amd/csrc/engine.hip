@@ -1,0 +1,405 @@
+// Native decoder runtime: owns the KV cache, the activation workspace and the kernel sequence of
+// ger/lora.py:504-549 (GPT.forward) + generate/base.py:57-80 (the decode loop) for a packed,
+// ragged batch.  Host side is plain C++; the decode step is captured once into a hipGraph and
+// replayed, so a generated token costs one graph launch and no host synchronisation.
+#include <vector>
+
+#include "common.h"
+
+int dh_sample_impl(const dh_bf16* logits, int vocab, int64_t* tokens, int tok_ld, int32_t* length, int32_t* done,
+                   int n_seq, float temperature, int top_k, int64_t eos_id, uint64_t seed, int step,
+                   const int32_t* step_dev, void* stream);
+
+namespace {
+
+struct Timing {
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[4];
+    std::vector<hipEvent_t> pool;
+};
+
+}  // namespace
+
+struct dh_engine {
+    dh_model_desc d;
+    std::vector<dh_layer_weights> layers;
+    int max_batch = 0, s_max = 0, max_tokens = 0;
+    int qkv_dim = 0, kv_dim = 0;
+    // device memory
+    bf16_t *kc = nullptr, *vtc = nullptr;             // [L][B][G][S][HS], [L][B][G][HS][S]
+    bf16_t *x = nullptr, *xn = nullptr, *qkv = nullptr, *qrot = nullptr, *att = nullptr, *xa = nullptr,
+           *act = nullptr, *xlast = nullptr, *logits = nullptr;
+    int32_t *tok_slot = nullptr, *tok_pos = nullptr, *seq_meta = nullptr;   // seq_meta: 4 x [B]
+    int32_t *last_row = nullptr, *step_dev = nullptr;
+    int64_t* dec_ids = nullptr;
+    void* dec_work = nullptr;
+    int32_t* h_stage = nullptr;                         // pinned staging for the metadata
+    size_t cache_layer_elems = 0;
+    int64_t dev_bytes = 0;
+    // decode graph
+    hipStream_t gstream = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    struct { int64_t* tokens; int tok_ld; int32_t *length, *done; int n_seq, top_k; float temp; int64_t eos; uint64_t seed; } gkey{};
+    int last_ntok = 0;
+    Timing tm;
+};
+
+namespace {
+
+template <typename T>
+int dmalloc(dh_engine* e, T** p, size_t n) {
+    DH_HIP(hipMalloc((void**)p, n * sizeof(T)));
+    e->dev_bytes += (int64_t)(n * sizeof(T));
+    return 0;
+}
+
+// ids of the step, positions and lengths derived on device from (tokens, length)
+__global__ void decode_prep_kernel(const int64_t* __restrict__ tokens, int tok_ld, const int32_t* __restrict__ length,
+                                   int64_t* __restrict__ ids, int32_t* __restrict__ tok_slot,
+                                   int32_t* __restrict__ tok_pos, int32_t* __restrict__ kv_len, int32_t* step_dev,
+                                   int n_seq, int s_max) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_seq) {
+        int n = length[i];
+        n = n < 1 ? 1 : (n > s_max ? s_max : n);     // never index outside the cache
+        ids[i] = tokens[(size_t)i * tok_ld + n - 1];
+        tok_slot[i] = i;
+        tok_pos[i] = n - 1;
+        kv_len[i] = n;
+    }
+    if (i == 0) *step_dev += 1;
+}
+
+__global__ void gather_rows_kernel(const bf16_t* __restrict__ src, const int32_t* __restrict__ rows,
+                                   bf16_t* __restrict__ dst, int n, int d) {
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= n) return;
+    const uint4* s = reinterpret_cast<const uint4*>(src + (size_t)rows[wave] * d);
+    uint4* t = reinterpret_cast<uint4*>(dst + (size_t)wave * d);
+    for (int c = lane; c < d / 8; c += 64) t[c] = s[c];
+}
+
+struct TimeScope {
+    dh_engine* e; int which; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
+    TimeScope(dh_engine* e_, int w, hipStream_t s_) : e(e_), which(w), s(s_) {
+        if (!e->tm.on) return;
+        hipEventCreate(&a); hipEventCreate(&b);
+        hipEventRecord(a, s);
+    }
+    ~TimeScope() {
+        if (!a) return;
+        hipEventRecord(b, s);
+        e->tm.ev[which].push_back({a, b});
+    }
+};
+
+int linear(dh_engine* e, const bf16_t* x, const bf16_t* w, bf16_t* y, int M, int N, int K, int epi,
+           const bf16_t* w2, const bf16_t* xa, int xa_ld, const bf16_t* lb, int s0, int s1, const bf16_t* va,
+           const bf16_t* vb, const bf16_t* resid, hipStream_t s, bool timed) {
+    if (timed) {
+        TimeScope t(e, M <= 32 ? 1 : 0, s);
+        return dh_linear_bf16(x, w, y, M, N, K, epi, w2, xa, xa_ld, lb, e->d.lora_scale, s0, s1, va, vb, resid, s);
+    }
+    return dh_linear_bf16(x, w, y, M, N, K, epi, w2, xa, xa_ld, lb, e->d.lora_scale, s0, s1, va, vb, resid, s);
+}
+
+// The layer stack on n_tok packed tokens whose metadata is already on the device.
+// prefill: attention over (seq_slot, q_start, q_len, kv_pos0); decode: one token per sequence.
+int run_layers(dh_engine* e, const int64_t* ids, int n_tok, int n_seq, int max_q_len, bool decode, hipStream_t s) {
+    const dh_model_desc& D = e->d;
+    const int d = D.n_embd, I = D.intermediate, hs = D.head_size, H = D.n_head, G = D.n_groups;
+    int32_t* seq_slot = e->seq_meta;
+    int32_t* q_start = e->seq_meta + e->max_batch;
+    int32_t* q_len = e->seq_meta + 2 * e->max_batch;
+    int32_t* kv_pos0 = e->seq_meta + 3 * e->max_batch;   // decode: kv_len
+    int rc;
+    if ((rc = dh_embed_bf16(ids, D.wte, e->x, n_tok, d, D.wte_rows, s))) return rc;
+    for (int l = 0; l < D.n_layer; ++l) {
+        const dh_layer_weights& W = e->layers[l];
+        bf16_t* kc = e->kc + (size_t)l * e->cache_layer_elems;
+        bf16_t* vtc = e->vtc + (size_t)l * e->cache_layer_elems;
+        if ((rc = dh_rmsnorm_bf16(e->x, nullptr, W.norm_1, e->xn, nullptr, n_tok, d, D.norm_eps, s))) return rc;
+        if (W.attn_lora_a) {
+            if ((rc = linear(e, e->xn, W.attn_lora_a, e->xa, n_tok, 48, d, DH_EPI_PLAIN, nullptr, nullptr, 0, nullptr, 0, 0,
+                             nullptr, nullptr, nullptr, s, false))) return rc;
+            if ((rc = linear(e, e->xn, W.attn_w, e->qkv, n_tok, e->qkv_dim, d, DH_EPI_LORA, nullptr, e->xa, 48,
+                             W.attn_lora_b, d, d + e->kv_dim, nullptr, nullptr, nullptr, s, true))) return rc;
+        } else {
+            if ((rc = linear(e, e->xn, W.attn_w, e->qkv, n_tok, e->qkv_dim, d, DH_EPI_PLAIN, nullptr, nullptr, 0, nullptr,
+                             0, 0, nullptr, nullptr, nullptr, s, true))) return rc;
+        }
+        if ((rc = dh_qkv_rope_cache_bf16(e->qkv, D.rope_cos, D.rope_sin, e->tok_slot, e->tok_pos, e->qrot, kc, vtc, n_tok,
+                                         H, G, hs, e->s_max, s))) return rc;
+        if (decode) {
+            TimeScope t(e, 3, s);
+            if ((rc = dh_attn_decode_bf16(e->qrot, kc, vtc, seq_slot, kv_pos0, e->att, e->dec_work, n_seq, H, G, hs,
+                                          e->s_max, s))) return rc;
+        } else {
+            TimeScope t(e, 2, s);
+            if ((rc = dh_attn_prefill_bf16(e->qrot, kc, vtc, seq_slot, q_start, q_len, kv_pos0, e->att, n_seq, max_q_len,
+                                           H, G, hs, e->s_max, s))) return rc;
+        }
+        if (W.proj_lora_a) {
+            if ((rc = linear(e, e->att, W.proj_lora_a, e->xa, n_tok, 16, d, DH_EPI_PLAIN, nullptr, nullptr, 0, nullptr, 0, 0,
+                             nullptr, nullptr, nullptr, s, false))) return rc;
+            if ((rc = linear(e, e->att, W.proj_w, e->x, n_tok, d, d, DH_EPI_LORA, nullptr, e->xa, 16, W.proj_lora_b, d, d,
+                             nullptr, nullptr, e->x, s, true))) return rc;
+        } else {
+            if ((rc = linear(e, e->att, W.proj_w, e->x, n_tok, d, d, DH_EPI_PLAIN, nullptr, nullptr, 0, nullptr, 0, 0,
+                             nullptr, nullptr, e->x, s, true))) return rc;
+        }
+        if ((rc = dh_rmsnorm_bf16(e->x, nullptr, W.norm_2, e->xn, nullptr, n_tok, d, D.norm_eps, s))) return rc;
+        if ((rc = linear(e, e->xn, W.fc_1, e->act, n_tok, I, d, DH_EPI_SWIGLU, W.fc_2, nullptr, 0, nullptr, 0, 0, nullptr,
+                         nullptr, nullptr, s, true))) return rc;
+        if ((rc = linear(e, e->act, W.mlp_proj, e->x, n_tok, d, I, DH_EPI_PLAIN, nullptr, nullptr, 0, nullptr, 0, 0, nullptr,
+                         nullptr, e->x, s, true))) return rc;
+    }
+    return 0;
+}
+
+int head(dh_engine* e, const bf16_t* xrows, int rows, bf16_t* logits, hipStream_t s) {
+    const dh_model_desc& D = e->d;
+    int rc;
+    if ((rc = dh_rmsnorm_bf16(xrows, nullptr, D.ln_f, e->xn, nullptr, rows, D.n_embd, D.norm_eps, s))) return rc;
+    return linear(e, e->xn, D.lm_head, logits, rows, D.vocab, D.n_embd, DH_EPI_ADAPTER, nullptr, nullptr, 0, nullptr, 0, 0,
+                  D.adapter_scale, D.adapter_bias, nullptr, s, true);
+}
+
+int decode_step(dh_engine* e, int64_t* tokens, int tok_ld, int32_t* length, int32_t* done, int n_seq, float temperature,
+                int top_k, int64_t eos_id, uint64_t seed, hipStream_t s);
+
+}  // namespace
+
+extern "C" int dh_engine_create(const dh_model_desc* desc, int max_batch, int s_max, int max_tokens, dh_engine** out) {
+    DH_CHECK(desc && out, "dh_engine_create: null argument");
+    DH_CHECK(desc->head_size == 64 || desc->head_size == 128, "dh_engine_create: head_size %d unsupported", desc->head_size);
+    DH_CHECK(desc->n_head % desc->n_groups == 0, "dh_engine_create: n_head %% n_groups != 0");
+    DH_CHECK(desc->n_embd == desc->n_head * desc->head_size, "dh_engine_create: n_embd != n_head*head_size");
+    DH_CHECK(desc->n_embd % 64 == 0 && desc->intermediate % 64 == 0 && desc->vocab % 8 == 0, "dh_engine_create: dims must be multiples of 64");
+    DH_CHECK(s_max > 0 && s_max % 64 == 0 && s_max <= (desc->block_size + 63) / 64 * 64, "dh_engine_create: s_max=%d must be a multiple of 64 and <= block_size rounded up", s_max);
+    DH_CHECK(max_batch > 0 && max_tokens >= max_batch, "dh_engine_create: bad batch/token capacity");
+    DH_CHECK(desc->rope_cos && desc->rope_sin && desc->wte && desc->ln_f && desc->lm_head && desc->h_layers, "dh_engine_create: null weight pointer");
+    dh_engine* e = new dh_engine();
+    e->d = *desc;
+    e->layers.assign(desc->h_layers, desc->h_layers + desc->n_layer);
+    e->d.h_layers = nullptr;
+    e->max_batch = max_batch; e->s_max = s_max; e->max_tokens = max_tokens;
+    const int d = desc->n_embd, hs = desc->head_size, G = desc->n_groups, H = desc->n_head;
+    e->kv_dim = G * hs;
+    e->qkv_dim = (H + 2 * G) * hs;
+    e->cache_layer_elems = (size_t)max_batch * G * s_max * hs;
+    const size_t T = max_tokens;
+    int rc = 0;
+    rc |= dmalloc(e, &e->kc, e->cache_layer_elems * desc->n_layer);
+    rc |= dmalloc(e, &e->vtc, e->cache_layer_elems * desc->n_layer);
+    rc |= dmalloc(e, &e->x, T * d);
+    rc |= dmalloc(e, &e->xn, T * d);
+    rc |= dmalloc(e, &e->qkv, T * e->qkv_dim);
+    rc |= dmalloc(e, &e->qrot, T * d);
+    rc |= dmalloc(e, &e->att, T * d);
+    rc |= dmalloc(e, &e->xa, T * 48);
+    rc |= dmalloc(e, &e->act, T * desc->intermediate);
+    rc |= dmalloc(e, &e->xlast, (size_t)max_batch * d);
+    rc |= dmalloc(e, &e->logits, (size_t)max_batch * desc->vocab);
+    rc |= dmalloc(e, &e->tok_slot, T);
+    rc |= dmalloc(e, &e->tok_pos, T);
+    rc |= dmalloc(e, &e->seq_meta, (size_t)4 * max_batch);
+    rc |= dmalloc(e, &e->last_row, (size_t)max_batch);
+    rc |= dmalloc(e, &e->step_dev, 1);
+    rc |= dmalloc(e, &e->dec_ids, (size_t)max_batch);
+    const int64_t wb = dh_attn_decode_work_bytes(max_batch, H, hs, s_max);
+    if (!rc) { hipError_t he = hipMalloc(&e->dec_work, wb); if (he != hipSuccess) rc = 2; e->dev_bytes += wb; }
+    if (rc) { dh_set_error("dh_engine_create: device allocation failed (%s)", dh_last_error()); dh_engine_destroy(e); return 2; }
+    // the attention kernels rely on finite (zero) cache contents beyond the written positions
+    DH_HIP(hipMemset(e->kc, 0, e->cache_layer_elems * desc->n_layer * sizeof(bf16_t)));
+    DH_HIP(hipMemset(e->vtc, 0, e->cache_layer_elems * desc->n_layer * sizeof(bf16_t)));
+    DH_HIP(hipMemset(e->step_dev, 0, sizeof(int32_t)));
+    DH_HIP(hipHostMalloc((void**)&e->h_stage, (2 * T + 5 * (size_t)max_batch) * sizeof(int32_t)));
+    DH_HIP(hipStreamCreateWithFlags(&e->gstream, hipStreamNonBlocking));
+    DH_HIP(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
+    DH_HIP(hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming));
+    *out = e;
+    return 0;
+}
+
+extern "C" void dh_engine_destroy(dh_engine* e) {
+    if (!e) return;
+    if (e->gexec) hipGraphExecDestroy(e->gexec);
+    void* ptrs[] = {e->kc, e->vtc, e->x, e->xn, e->qkv, e->qrot, e->att, e->xa, e->act, e->xlast, e->logits,
+                    e->tok_slot, e->tok_pos, e->seq_meta, e->last_row, e->step_dev, e->dec_ids, e->dec_work};
+    for (void* p : ptrs)
+        if (p) hipFree(p);
+    if (e->h_stage) hipHostFree(e->h_stage);
+    if (e->gstream) hipStreamDestroy(e->gstream);
+    if (e->ev_in) hipEventDestroy(e->ev_in);
+    if (e->ev_out) hipEventDestroy(e->ev_out);
+    for (auto& v : e->tm.ev)
+        for (auto& p : v) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    delete e;
+}
+
+extern "C" int64_t dh_engine_device_bytes(const dh_engine* e) { return e ? e->dev_bytes : 0; }
+extern "C" int dh_engine_read(dh_engine* e, int what, int layer, void* dst, int64_t n_bytes, void* stream) {
+    DH_CHECK(e && dst && n_bytes >= 0, "dh_engine_read: bad argument");
+    const void* src = nullptr;
+    int64_t avail = 0;
+    const int64_t cache_bytes = (int64_t)e->cache_layer_elems * sizeof(bf16_t);
+    switch (what) {
+        case 0: src = e->xn; avail = (int64_t)e->max_tokens * e->d.n_embd * 2; break;
+        case 3: src = e->x; avail = (int64_t)e->max_tokens * e->d.n_embd * 2; break;
+        case 1: case 2:
+            DH_CHECK(layer >= 0 && layer < e->d.n_layer, "dh_engine_read: layer %d out of range", layer);
+            src = (what == 1 ? e->kc : e->vtc) + (size_t)layer * e->cache_layer_elems;
+            avail = cache_bytes;
+            break;
+        default: DH_CHECK(false, "dh_engine_read: unknown selector %d", what);
+    }
+    DH_CHECK(n_bytes <= avail, "dh_engine_read: %lld bytes requested, %lld available", (long long)n_bytes, (long long)avail);
+    DH_HIP(hipMemcpyAsync(dst, src, n_bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int dh_engine_forward(dh_engine* e, const int64_t* ids, const int32_t* h_seq_len, const int32_t* h_pos0,
+                                 int n_seq, dh_bf16* logits_all, dh_bf16* logits_last, void* stream) {
+    DH_CHECK(e && ids && h_seq_len && h_pos0, "dh_engine_forward: null argument");
+    DH_CHECK(n_seq > 0 && n_seq <= e->max_batch, "dh_engine_forward: n_seq=%d exceeds max_batch=%d", n_seq, e->max_batch);
+    hipStream_t s = (hipStream_t)stream;
+    int n_tok = 0, max_q = 0;
+    for (int i = 0; i < n_seq; ++i) {
+        DH_CHECK(h_seq_len[i] > 0 && h_pos0[i] >= 0, "dh_engine_forward: sequence %d has length %d at position %d", i, h_seq_len[i], h_pos0[i]);
+        DH_CHECK(h_pos0[i] + h_seq_len[i] <= e->s_max, "Cannot forward sequence %d: %d tokens at position %d exceed the KV cache length %d",
+                 i, h_seq_len[i], h_pos0[i], e->s_max);
+        n_tok += h_seq_len[i];
+        max_q = h_seq_len[i] > max_q ? h_seq_len[i] : max_q;
+    }
+    DH_CHECK(n_tok <= e->max_tokens, "dh_engine_forward: %d tokens exceed the workspace capacity %d", n_tok, e->max_tokens);
+    // metadata: [tok_slot | tok_pos | seq_slot | q_start | q_len | kv_pos0 | last_row]
+    const int B = e->max_batch;
+    int32_t* hs_ = e->h_stage;
+    DH_HIP(hipStreamSynchronize(s));   // the pinned staging buffer may still be in flight from the previous call
+    int32_t *h_slot = hs_, *h_pos = hs_ + e->max_tokens, *h_meta = hs_ + 2 * (size_t)e->max_tokens;
+    int t = 0;
+    for (int i = 0; i < n_seq; ++i) {
+        h_meta[i] = i;
+        h_meta[B + i] = t;
+        h_meta[2 * B + i] = h_seq_len[i];
+        h_meta[3 * B + i] = h_pos0[i];
+        for (int j = 0; j < h_seq_len[i]; ++j, ++t) { h_slot[t] = i; h_pos[t] = h_pos0[i] + j; }
+        h_meta[4 * B + i] = t - 1;
+    }
+    DH_HIP(hipMemcpyAsync(e->tok_slot, h_slot, n_tok * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    DH_HIP(hipMemcpyAsync(e->tok_pos, h_pos, n_tok * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    DH_HIP(hipMemcpyAsync(e->seq_meta, h_meta, 4 * B * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    DH_HIP(hipMemcpyAsync(e->last_row, h_meta + 4 * B, B * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    int rc;
+    if ((rc = run_layers(e, ids, n_tok, n_seq, max_q, false, s))) return rc;
+    e->last_ntok = n_tok;
+    if (logits_all) {
+        // ln_f output lands in e->xn (test hook dh_engine_hidden)
+        if ((rc = head(e, e->x, n_tok, logits_all, s))) return rc;
+    }
+    if (logits_last) {
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(n_seq, 4)), dim3(256), 0, s, e->x, e->last_row, e->xlast, n_seq,
+                           e->d.n_embd);
+        DH_LAUNCH_CHECK();
+        if (logits_all) {
+            // xn currently holds ln_f(x) of all rows; recompute for the gathered rows into a scratch
+            // region past them is unnecessary: head() overwrites xn[0:n_seq], which is fine after logits_all.
+        }
+        if ((rc = head(e, e->xlast, n_seq, logits_last, s))) return rc;
+    }
+    return 0;
+}
+
+namespace {
+
+int decode_step(dh_engine* e, int64_t* tokens, int tok_ld, int32_t* length, int32_t* done, int n_seq, float temperature,
+                int top_k, int64_t eos_id, uint64_t seed, hipStream_t s) {
+    int32_t* kv_len = e->seq_meta + 3 * e->max_batch;
+    hipLaunchKernelGGL(decode_prep_kernel, dim3(cdiv(n_seq, 64)), dim3(64), 0, s, tokens, tok_ld, length, e->dec_ids,
+                       e->tok_slot, e->tok_pos, kv_len, e->step_dev, n_seq, e->s_max);
+    DH_LAUNCH_CHECK();
+    int rc;
+    if ((rc = run_layers(e, e->dec_ids, n_seq, n_seq, 1, true, s))) return rc;
+    if ((rc = head(e, e->x, n_seq, e->logits, s))) return rc;
+    // the per-step RNG counter lives in step_dev (incremented by decode_prep_kernel)
+    return dh_sample_impl(e->logits, e->d.vocab, tokens, tok_ld, length, done, n_seq, temperature, top_k, eos_id,
+                          seed, 0, e->step_dev, s);
+}
+
+}  // namespace
+
+extern "C" int dh_engine_decode(dh_engine* e, int64_t* tokens, int tok_ld, int32_t* length, int32_t* done, int n_seq,
+                                int n_steps, float temperature, int top_k, int64_t eos_id, uint64_t seed,
+                                int first_step, void* stream) {
+    DH_CHECK(e && tokens && length && done, "dh_engine_decode: null argument");
+    DH_CHECK(n_seq > 0 && n_seq <= e->max_batch, "dh_engine_decode: n_seq=%d exceeds max_batch=%d", n_seq, e->max_batch);
+    DH_CHECK(temperature > 0.f && top_k >= 0, "dh_engine_decode: bad sampling parameters");
+    if (n_steps <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    // seq_slot identity for the decode attention
+    {
+        DH_HIP(hipStreamSynchronize(s));
+        int32_t* h_meta = e->h_stage;
+        for (int i = 0; i < n_seq; ++i) h_meta[i] = i;
+        DH_HIP(hipMemcpyAsync(e->seq_meta, h_meta, n_seq * sizeof(int32_t), hipMemcpyHostToDevice, s));
+        int32_t fs = first_step;
+        h_meta[e->max_batch] = fs;
+        DH_HIP(hipMemcpyAsync(e->step_dev, h_meta + e->max_batch, sizeof(int32_t), hipMemcpyHostToDevice, s));
+    }
+    if (e->tm.on) {  // timed runs stay eager so each kernel class can be bracketed by events
+        for (int i = 0; i < n_steps; ++i) {
+            int rc = decode_step(e, tokens, tok_ld, length, done, n_seq, temperature, top_k, eos_id, seed, s);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    const bool same = e->gexec && e->gkey.tokens == tokens && e->gkey.tok_ld == tok_ld && e->gkey.length == length &&
+                      e->gkey.done == done && e->gkey.n_seq == n_seq && e->gkey.top_k == top_k &&
+                      e->gkey.temp == temperature && e->gkey.eos == eos_id && e->gkey.seed == seed;
+    // hand over from the caller's stream to the engine's capture-capable stream
+    DH_HIP(hipEventRecord(e->ev_in, s));
+    DH_HIP(hipStreamWaitEvent(e->gstream, e->ev_in, 0));
+    if (!same) {
+        if (e->gexec) { hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
+        hipGraph_t graph = nullptr;
+        DH_HIP(hipStreamBeginCapture(e->gstream, hipStreamCaptureModeThreadLocal));
+        int rc = decode_step(e, tokens, tok_ld, length, done, n_seq, temperature, top_k, eos_id, seed, e->gstream);
+        hipError_t ce = hipStreamEndCapture(e->gstream, &graph);
+        if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+        DH_CHECK(ce == hipSuccess && graph, "dh_engine_decode: graph capture failed: %s", hipGetErrorString(ce));
+        hipError_t ie = hipGraphInstantiate(&e->gexec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        DH_CHECK(ie == hipSuccess, "dh_engine_decode: hipGraphInstantiate failed: %s", hipGetErrorString(ie));
+        e->gkey = {tokens, tok_ld, length, done, n_seq, top_k, temperature, eos_id, seed};
+    }
+    for (int i = 0; i < n_steps; ++i) DH_HIP(hipGraphLaunch(e->gexec, e->gstream));
+    DH_HIP(hipEventRecord(e->ev_out, e->gstream));
+    DH_HIP(hipStreamWaitEvent(s, e->ev_out, 0));
+    return 0;
+}
+
+extern "C" int dh_engine_set_timing(dh_engine* e, int on) {
+    DH_CHECK(e, "dh_engine_set_timing: null engine");
+    e->tm.on = on != 0;
+    for (auto& v : e->tm.ev) {
+        for (auto& p : v) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+        v.clear();
+    }
+    return 0;
+}
+
+extern "C" int dh_engine_get_timing(dh_engine* e, int which, double* h_ms, int64_t* h_launches) {
+    DH_CHECK(e && which >= 0 && which < 4 && h_ms && h_launches, "dh_engine_get_timing: bad argument");
+    DH_HIP(hipDeviceSynchronize());
+    double tot = 0;
+    for (auto& p : e->tm.ev[which]) {
+        float ms = 0;
+        DH_HIP(hipEventElapsedTime(&ms, p.first, p.second));
+        tot += ms;
+    }
+    *h_ms = tot;
+    *h_launches = (int64_t)e->tm.ev[which].size();
+    return 0;
+}

@@ -1,0 +1,267 @@
+// y[M,N] = epilogue(x[M,K] · W[N,K]^T) on the gfx950 matrix cores.
+//
+// Both operands are K-contiguous, so each MFMA fragment is one 16-byte run of a row.  The kernel
+// computes C^T tiles: the A operand is a 32-row slab of W (rows = n), the B operand a 32-row slab
+// of x (cols = m); a lane of the 32x32 accumulator then owns 4 consecutive n for one m, which
+// makes the epilogue (LoRA rank-16 update, SwiGLU pairing, adapter scale/bias, residual add) a
+// per-lane affair with 8-byte row-contiguous loads/stores.
+//
+//   block  : 256 threads = 4 waves as 2(n) x 2(m); block tile 128(n) x 128(m), BK = 64
+//   wave   : 64 x 64 = 2 x 2 MFMA 32x32x16 tiles, 64 accumulator VGPRs
+//   LDS    : 2 stages x (W tile 16 KiB + x tile 16 KiB) = 64 KiB -> 2 blocks / CU
+//   staging: global_load_lds 16 B/lane (LDS image is lane-linear, so the bank swizzle
+//            chunk ^= (row>>1)&7 is applied to the SOURCE address and again on the ds_read)
+//   grid   : 1-D, remapped so each XCD (blocks b, b+8, ...) owns a contiguous band of tiles
+//
+// LoRA fused as a rank-16 epilogue (ger/lora.py:159-166, 388-402): xa = bf16(x·A^T) is computed
+// beforehand ([M,16*segments]); each 32x32 output tile then needs ONE extra MFMA
+// lacc = lora_B[32 n,16] · xa[32 m,16]^T, and y = bf16(bf16(acc) + bf16(bf16(lacc)*s)).
+#include "common.h"
+
+namespace {
+
+struct GemmArgs {
+    const bf16_t* x;
+    const bf16_t* w;
+    const bf16_t* w2;
+    bf16_t* y;
+    const bf16_t* xa;
+    const bf16_t* lora_b;
+    const bf16_t* vec_a;
+    const bf16_t* vec_b;
+    const bf16_t* resid;
+    int M, N, K;
+    int xa_ld, split0, split1;
+    float lora_scale;
+    int nb_n, nb_m;
+};
+
+constexpr int BT = 128;   // block tile edge (both n and m)
+constexpr int BK = 64;
+constexpr int TILE_BYTES = BT * BK * 2;  // 16 KiB
+
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+
+template <int EPI, bool RESID>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wm = wave & 1;
+
+    // XCD-aware tile order: blocks b, b+8, b+16.. share an XCD -> give them neighbouring tiles
+    const int nwg = a.nb_n * a.nb_m;
+    int tile;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tm = tile / a.nb_n, tn = tile % a.nb_n;
+    const int m0 = tm * BT;
+    // SWIGLU: 64 rows of fc_1 and the same 64 rows of fc_2 per block
+    const int n0 = (EPI == DH_EPI_SWIGLU) ? tn * 64 : tn * BT;
+
+    // ---- per-lane source rows for the 4+4 staging instructions of this wave
+    const bf16_t* srcA[4];
+    const bf16_t* srcB[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int R = wave * 4 + j;               // 1-KiB row group: LDS rows R*8 .. R*8+7
+        const int row = R * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ swz(row);  // logical 16-B chunk held by this LDS slot
+        {
+            const bf16_t* base = a.w;
+            int n;
+            if (EPI == DH_EPI_SWIGLU) {
+                const int half = (row >> 5) & 1;  // 32-row MFMA tile parity: 0 = fc_1, 1 = fc_2
+                n = n0 + (row >> 6) * 32 + (row & 31);
+                base = half ? a.w2 : a.w;
+            } else {
+                n = n0 + row;
+            }
+            n = n < a.N ? n : a.N - 1;
+            srcA[j] = base + (size_t)n * a.K + chunk * 8;
+        }
+        {
+            int m = m0 + row;
+            m = m < a.M ? m : a.M - 1;
+            srcB[j] = a.x + (size_t)m * a.K + chunk * 8;
+        }
+    }
+    auto stage = [&](int buf, int kt) {
+        char* sA = smem + buf * 2 * TILE_BYTES;
+        char* sB = sA + TILE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int R = wave * 4 + j;
+            glds16(srcA[j] + kt * BK, sA + R * 1024);
+            glds16(srcB[j] + kt * BK, sB + R * 1024);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment read offsets (bytes) inside a tile; (row>>1)&7 only depends on the lane here
+    const int lr = lane & 31, lh = lane >> 5;
+    int offA[2], offB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        offA[i] = (wn * 64 + i * 32 + lr) * 128;
+        offB[i] = (wm * 64 + i * 32 + lr) * 128;
+    }
+    const int sw = swz(lr);
+
+    const int nk = a.K / BK;
+    stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* sA = smem + cur * 2 * TILE_BYTES;
+        const char* sB = sA + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int co = (((ks * 2 + lh) ^ sw) << 4);
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[i] = *reinterpret_cast<const bf16x8*>(sA + offA[i] + co);
+                fb[i] = *reinterpret_cast<const bf16x8*>(sB + offB[i] + co);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();  // drains the stage's vmcnt and fences the buffer swap
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    // accumulator element r of tile (i,j): n = nt + (r&3) + 8*(r>>2) + 4*lh ; m = mt + lr
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = m0 + wm * 64 + j * 32 + lr;
+        const bool m_ok = m < a.M;
+        if (EPI == DH_EPI_SWIGLU) {
+            const int nt = n0 + wn * 32;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int n = nt + 8 * rg + 4 * lh;
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float g = rbf(acc[0][j][rg * 4 + e]);
+                    const float u = rbf(acc[1][j][rg * 4 + e]);
+                    const float s = rbf(g / (1.0f + expf(-g)));
+                    o[e] = s * u;
+                }
+                if (m_ok && n < a.N) {
+                    uint2 pk = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+                    *reinterpret_cast<uint2*>(a.y + (size_t)m * a.N + n) = pk;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int nt = n0 + wn * 64 + i * 32;
+                f32x16 lacc;
+                if (EPI == DH_EPI_LORA) {
+                    const int seg = (nt >= a.split0) + (nt >= a.split1);
+                    int nn = nt + lr;
+                    nn = nn < a.N ? nn : a.N - 1;
+                    const int mm = m_ok ? m : a.M - 1;
+                    const bf16x8 lb = *reinterpret_cast<const bf16x8*>(a.lora_b + (size_t)nn * 16 + lh * 8);
+                    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(a.xa + (size_t)mm * a.xa_ld + seg * 16 + lh * 8);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
+                    lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lb, xf, lacc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int n = nt + 8 * rg + 4 * lh;
+                    if (!(m_ok && n < a.N)) continue;
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = rbf(acc[i][j][rg * 4 + e]);
+                    if (EPI == DH_EPI_LORA) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = rbf(o[e] + rbf(rbf(lacc[rg * 4 + e]) * a.lora_scale));
+                    }
+                    if (EPI == DH_EPI_ADAPTER) {
+                        const uint2 sc = *reinterpret_cast<const uint2*>(a.vec_a + n);
+                        const uint2 bi = *reinterpret_cast<const uint2*>(a.vec_b + n);
+                        const bf16_t* sp = reinterpret_cast<const bf16_t*>(&sc);
+                        const bf16_t* bp = reinterpret_cast<const bf16_t*>(&bi);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = rbf(bf2f(sp[e]) * rbf(o[e] + bf2f(bp[e])));
+                    }
+                    if (RESID) {
+                        const uint2 rr = *reinterpret_cast<const uint2*>(a.resid + (size_t)m * a.N + n);
+                        const bf16_t* rp = reinterpret_cast<const bf16_t*>(&rr);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = bf2f(rp[e]) + o[e];
+                    }
+                    uint2 pk = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+                    *reinterpret_cast<uint2*>(a.y + (size_t)m * a.N + n) = pk;
+                }
+            }
+        }
+    }
+}
+
+template <int EPI>
+int launch(const GemmArgs& a, hipStream_t s) {
+    dim3 grid(a.nb_n * a.nb_m), block(256);
+    if (a.resid)
+        hipLaunchKernelGGL((gemm_nt_kernel<EPI, true>), grid, block, 0, s, a);
+    else
+        hipLaunchKernelGGL((gemm_nt_kernel<EPI, false>), grid, block, 0, s, a);
+    DH_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int dh_linear_bf16(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N, int K, int epilogue,
+                              const dh_bf16* w2, const dh_bf16* xa, int xa_ld, const dh_bf16* lora_b,
+                              float lora_scale, int split0, int split1, const dh_bf16* vec_a,
+                              const dh_bf16* vec_b, const dh_bf16* resid, void* stream) {
+    DH_CHECK(M >= 0 && N > 0 && K > 0, "dh_linear_bf16: bad shape M=%d N=%d K=%d", M, N, K);
+    DH_CHECK(K % BK == 0, "dh_linear_bf16: K=%d must be a multiple of %d", K, BK);
+    DH_CHECK(N % 8 == 0, "dh_linear_bf16: N=%d must be a multiple of 8", N);
+    DH_CHECK(x && w && y, "dh_linear_bf16: null operand");
+    if (M == 0) return 0;
+    GemmArgs a;
+    a.x = x; a.w = w; a.w2 = w2; a.y = y; a.xa = xa; a.lora_b = lora_b; a.vec_a = vec_a; a.vec_b = vec_b;
+    a.resid = resid; a.M = M; a.N = N; a.K = K; a.xa_ld = xa_ld; a.split0 = split0; a.split1 = split1;
+    a.lora_scale = lora_scale;
+    a.nb_m = cdiv(M, BT);
+    a.nb_n = (epilogue == DH_EPI_SWIGLU) ? cdiv(N, 64) : cdiv(N, BT);
+    hipStream_t s = (hipStream_t)stream;
+    switch (epilogue) {
+        case DH_EPI_PLAIN:
+            return launch<DH_EPI_PLAIN>(a, s);
+        case DH_EPI_LORA:
+            DH_CHECK(xa && lora_b && xa_ld >= 16 && xa_ld % 8 == 0, "dh_linear_bf16: LORA epilogue needs xa/lora_b");
+            DH_CHECK(split0 % 32 == 0 && split1 % 32 == 0 && split0 <= split1, "dh_linear_bf16: LoRA splits must be multiples of 32");
+            DH_CHECK(xa_ld >= 16 * (1 + (split0 < N) + (split1 < N)), "dh_linear_bf16: xa_ld too small for the segments");
+            return launch<DH_EPI_LORA>(a, s);
+        case DH_EPI_SWIGLU:
+            DH_CHECK(w2 != nullptr, "dh_linear_bf16: SWIGLU epilogue needs w2");
+            DH_CHECK(resid == nullptr, "dh_linear_bf16: SWIGLU epilogue takes no residual");
+            DH_CHECK(N % 32 == 0, "dh_linear_bf16: SWIGLU needs N %% 32 == 0");
+            return launch<DH_EPI_SWIGLU>(a, s);
+        case DH_EPI_ADAPTER:
+            DH_CHECK(vec_a && vec_b, "dh_linear_bf16: ADAPTER epilogue needs scale/bias vectors");
+            return launch<DH_EPI_ADAPTER>(a, s);
+        default:
+            DH_CHECK(false, "dh_linear_bf16: unknown epilogue %d", epilogue);
+    }
+    return 0;
+}

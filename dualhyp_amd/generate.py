@@ -1,0 +1,67 @@
+"""The decode loop of the reference (generate/base.py:19-82), batched and kept on the device.
+
+`generate()` has the reference's signature and semantics for one prompt (EOS excluded from the
+result, quirk Q7; `top_k=1` is a deterministic lowest-index arg-max instead of a sampled tie
+break, quirk Q6).  `generate_batch()` runs many ragged prompts at once — equal to running each
+alone — with one packed prefill and one hipGraph launch per generated token; the host reads the
+device state back once at the end instead of once per token (generate/base.py:79).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import ops
+from .gpt import GPT
+
+
+@torch.inference_mode()
+def generate_batch(model: GPT, prompts: Sequence[torch.Tensor], max_new_tokens: int, *, temperature: float = 1.0,
+                   top_k: Optional[int] = None, eos_id: Optional[int] = None, seed: int = 1337,
+                   return_state: bool = False):
+    """prompts: 1-D int64 tensors (any lengths).  Returns a list of 1-D tensors prompt+generated,
+    cut before the EOS token when one was produced."""
+    B = len(prompts)
+    assert B > 0 and max_new_tokens > 0
+    lens = [int(p.numel()) for p in prompts]
+    T_max = max(lens)
+    need_pos = T_max + max_new_tokens - 1
+    if model.max_seq_length < need_pos:
+        raise NotImplementedError(f"max_seq_length {model.max_seq_length} needs to be >= {need_pos}")
+    dev = model.transformer.wte.weight.device
+    eng = model.engine(B, need_pos, sum(lens))
+    tok_ld = T_max + max_new_tokens
+    tokens = torch.zeros((B, tok_ld), dtype=torch.int64, device=dev)
+    for i, p in enumerate(prompts):
+        tokens[i, : lens[i]] = p.to(dev)
+    length = torch.tensor(lens, dtype=torch.int32, device=dev)
+    done = torch.zeros(B, dtype=torch.int32, device=dev)
+    packed = torch.cat([p.to(dev).reshape(-1) for p in prompts])
+    _, last = eng.forward(packed, lens, [0] * B, want_all=False, want_last=True)
+    ops.sample(last, tokens, length, done, temperature=temperature, top_k=top_k, eos_id=eos_id, seed=seed, step=0)
+    if max_new_tokens > 1:
+        eng.decode(tokens, length, done, max_new_tokens - 1, temperature, top_k, eos_id, seed, first_step=0)
+    model._cache_len = []  # slots now hold these sequences; a later cached forward must start at 0
+    length_h = length.tolist()          # the one host read-back
+    done_h = done.tolist()
+    out: List[torch.Tensor] = []
+    for i in range(B):
+        n = min(length_h[i], lens[i] + max_new_tokens)
+        if done_h[i] == 1:
+            n -= 1                      # generate/base.py:80 returns idx[:input_pos]: EOS excluded
+        out.append(tokens[i, :n].clone())
+    if return_state:
+        return out, dict(tokens=tokens, length=length, done=done)
+    return out
+
+
+@torch.inference_mode()
+def generate(model: GPT, idx: torch.Tensor, max_returned_tokens: int, *, temperature: float = 1.0,
+             top_k: Optional[int] = None, eos_id: Optional[int] = None) -> torch.Tensor:
+    """Drop-in for generate/base.py:generate (one prompt of shape (T,))."""
+    T = idx.size(0)
+    assert max_returned_tokens > T
+    if model.max_seq_length < max_returned_tokens - 1:
+        raise NotImplementedError(f"max_seq_length {model.max_seq_length} needs to be >= {max_returned_tokens - 1}")
+    return generate_batch(model, [idx], max_returned_tokens - T, temperature=temperature, top_k=top_k, eos_id=eos_id)[0]

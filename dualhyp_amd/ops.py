@@ -1,0 +1,134 @@
+"""Tensor-level wrappers over the C ABI (include/dualhyp_hip.h).
+
+Every function takes CUDA (ROCm) bf16/int tensors, launches on torch's current stream and
+returns torch tensors.  They are thin: shape checks + pointer passing.  No fallbacks — a CPU
+tensor or a missing library raises.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check
+
+EPI_PLAIN, EPI_LORA, EPI_SWIGLU, EPI_ADAPTER = 0, 1, 2, 3
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, dtype=torch.bfloat16, name="tensor") -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.DualHypHipError(f"{name} must live on the GPU: the HIP path has no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def embed(ids: torch.Tensor, wte: torch.Tensor) -> torch.Tensor:
+    ids = _dev(ids.reshape(-1), torch.int64, "ids")
+    wte = _dev(wte, name="wte")
+    out = torch.empty((ids.numel(), wte.size(1)), dtype=torch.bfloat16, device=wte.device)
+    check(_lib.load().dh_embed_bf16(_p(ids), _p(wte), _p(out), ids.numel(), wte.size(1), wte.size(0), _stream()))
+    return out
+
+
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, resid: Optional[torch.Tensor] = None,
+            return_sum: bool = False):
+    x = _dev(x, name="x")
+    w = _dev(w, name="weight")
+    d = x.size(-1)
+    rows = x.numel() // d
+    out = torch.empty_like(x)
+    s = torch.empty_like(x) if (resid is not None and return_sum) else None
+    if resid is not None:
+        resid = _dev(resid, name="resid")
+    check(_lib.load().dh_rmsnorm_bf16(_p(x), _p(resid), _p(w), _p(out), _p(s), rows, d, float(eps), _stream()))
+    return (out, s) if return_sum else out
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, *, epilogue: int = EPI_PLAIN, w2: Optional[torch.Tensor] = None,
+           xa: Optional[torch.Tensor] = None, lora_b: Optional[torch.Tensor] = None, lora_scale: float = 1.0,
+           splits: Optional[Tuple[int, int]] = None, scale: Optional[torch.Tensor] = None,
+           bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = epilogue(x @ w.T); see dh_linear_bf16 in include/dualhyp_hip.h."""
+    x = _dev(x, name="x")
+    w = _dev(w, name="w")
+    K = x.size(-1)
+    M = x.numel() // K
+    N = w.size(0)
+    assert w.size(1) == K, f"weight is {tuple(w.shape)}, input feature size {K}"
+    y = out if out is not None else torch.empty((*x.shape[:-1], N), dtype=torch.bfloat16, device=x.device)
+    s0, s1 = splits if splits is not None else (N, N)
+    xa_ld = 0
+    if xa is not None:
+        xa = _dev(xa, name="xa")
+        xa_ld = xa.size(-1)
+    for t, nm in ((w2, "w2"), (lora_b, "lora_b"), (scale, "scale"), (bias, "bias"), (resid, "resid")):
+        if t is not None:
+            _dev(t, name=nm)
+            assert t.is_contiguous(), f"{nm} must be contiguous"
+    check(_lib.load().dh_linear_bf16(_p(x), _p(w), _p(y), M, N, K, epilogue, _p(w2), _p(xa), xa_ld, _p(lora_b),
+                                     float(lora_scale), s0, s1, _p(scale), _p(bias), _p(resid), _stream()))
+    return y
+
+
+def qkv_rope_cache(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, tok_slot: torch.Tensor,
+                   tok_pos: torch.Tensor, k_cache: torch.Tensor, vT_cache: torch.Tensor, n_head: int,
+                   n_groups: int) -> torch.Tensor:
+    """-> rotated q [n_tok, n_head, hs]; appends k / v^T into the caches in place."""
+    qkv = _dev(qkv, name="qkv")
+    hs = k_cache.size(-1)
+    s_max = k_cache.size(-2)
+    n_tok = qkv.numel() // ((n_head + 2 * n_groups) * hs)
+    q = torch.empty((n_tok, n_head, hs), dtype=torch.bfloat16, device=qkv.device)
+    check(_lib.load().dh_qkv_rope_cache_bf16(_p(qkv), _p(_dev(cos)), _p(_dev(sin)), _p(_dev(tok_slot, torch.int32)),
+                                             _p(_dev(tok_pos, torch.int32)), _p(q), _p(k_cache), _p(vT_cache), n_tok,
+                                             n_head, n_groups, hs, s_max, _stream()))
+    return q
+
+
+def attn_prefill(q: torch.Tensor, k_cache: torch.Tensor, vT_cache: torch.Tensor, seq_slot: torch.Tensor,
+                 q_start: torch.Tensor, q_len: torch.Tensor, kv_pos0: torch.Tensor, max_q_len: int) -> torch.Tensor:
+    n_tok, n_head, hs = q.shape
+    n_groups, s_max = k_cache.size(1), k_cache.size(2)
+    y = torch.empty((n_tok, n_head * hs), dtype=torch.bfloat16, device=q.device)
+    i32 = torch.int32
+    check(_lib.load().dh_attn_prefill_bf16(_p(_dev(q)), _p(k_cache), _p(vT_cache), _p(_dev(seq_slot, i32)),
+                                           _p(_dev(q_start, i32)), _p(_dev(q_len, i32)), _p(_dev(kv_pos0, i32)), _p(y),
+                                           seq_slot.numel(), int(max_q_len), n_head, n_groups, hs, s_max, _stream()))
+    return y
+
+
+def attn_decode(q: torch.Tensor, k_cache: torch.Tensor, vT_cache: torch.Tensor, seq_slot: torch.Tensor,
+                kv_len: torch.Tensor) -> torch.Tensor:
+    n_seq, n_head, hs = q.shape
+    n_groups, s_max = k_cache.size(1), k_cache.size(2)
+    lib = _lib.load()
+    work = torch.empty(lib.dh_attn_decode_work_bytes(n_seq, n_head, hs, s_max), dtype=torch.uint8, device=q.device)
+    y = torch.empty((n_seq, n_head * hs), dtype=torch.bfloat16, device=q.device)
+    i32 = torch.int32
+    check(lib.dh_attn_decode_bf16(_p(_dev(q)), _p(k_cache), _p(vT_cache), _p(_dev(seq_slot, i32)),
+                                  _p(_dev(kv_len, i32)), _p(y), _p(work), n_seq, n_head, n_groups, hs, s_max, _stream()))
+    return y
+
+
+def sample(logits: torch.Tensor, tokens: torch.Tensor, length: torch.Tensor, done: torch.Tensor, *,
+           temperature: float = 1.0, top_k: Optional[int] = None, eos_id: Optional[int] = None, seed: int = 0,
+           step: int = 0) -> None:
+    """Append one token per sequence in place (tokens/length/done); see dh_sample_bf16."""
+    logits = _dev(logits, name="logits")
+    n_seq, vocab = logits.shape
+    assert tokens.dtype == torch.int64 and tokens.is_contiguous() and tokens.size(0) == n_seq
+    check(_lib.load().dh_sample_bf16(_p(logits), vocab, _p(tokens), tokens.size(1), _p(_dev(length, torch.int32)),
+                                     _p(_dev(done, torch.int32)), n_seq, float(temperature),
+                                     0 if top_k is None else int(top_k), -1 if eos_id is None else int(eos_id),
+                                     int(seed) & ((1 << 64) - 1), int(step), _stream()))

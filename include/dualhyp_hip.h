@@ -1,0 +1,201 @@
+/*
+ * dualhyp_hip.h — C ABI of libdualhyp_hip.so: the MI355X (gfx950) implementation of DualHyp's
+ * LLM hot path.  Plain pointers and sizes only; every pointer is a DEVICE pointer unless the
+ * parameter name starts with `h_`.  `stream` is a hipStream_t passed as void* (NULL = default
+ * stream).  Every function returns 0 on success; on failure it returns non-zero and
+ * dh_last_error() describes it (thread-local).  Nothing here allocates unless it says so.
+ *
+ * The reference has no FFI: its boundary for this path is the Python class API
+ * (ger/lora.py GPT.forward, generate/base.py generate).  Each entry point below replaces the
+ * tensor program one reference function expands to on CPU/CUDA; the reference file:line is
+ * given per function.  INTEGRATION.md shows the ctypes binding a maintainer of the reference
+ * would add.
+ *
+ * dtype: bf16 = uint16_t bit pattern (storage dtype of the reference's bf16-true mode); all
+ * accumulation is fp32; results are rounded to bf16 at exactly the points where the
+ * reference's eager bf16 tensor program rounds.
+ */
+#ifndef DUALHYP_HIP_H
+#define DUALHYP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint16_t dh_bf16;
+
+#define DH_ABI_VERSION 1
+
+int dh_abi_version(void);
+const char* dh_last_error(void);
+/* Name of the first visible device's gcnArch ("gfx950") into buf; fails when no GPU. */
+int dh_device_info(char* h_buf, int h_buf_len, int* h_num_cu, int64_t* h_hbm_bytes);
+
+/* ------------------------------------------------------------------ elementwise / layout */
+
+/* out[t,:] = wte[ids[t],:]            — nn.Embedding, ger/lora.py:537 */
+int dh_embed_bf16(const int64_t* ids, const dh_bf16* wte, dh_bf16* out, int n_tok, int d,
+                  int vocab, void* stream);
+
+/* RMSNorm in the storage dtype — ger/rmsnorm.py:17-21:
+ *   ms = bf16(mean_fp32(bf16(x*x))) ; r = bf16(rsqrt(bf16(ms+eps))) ; out = bf16(w*bf16(x*r))
+ * If `resid` is non-NULL the input is x := bf16(x + resid) and `sum_out` (if non-NULL)
+ * receives that sum (the residual stream update of ger/model.py:185-186). */
+int dh_rmsnorm_bf16(const dh_bf16* x, const dh_bf16* resid, const dh_bf16* w, dh_bf16* out,
+                    dh_bf16* sum_out, int rows, int d, float eps, void* stream);
+
+/* Split the fused QKV projection, rotate q and k, append k/v to the KV cache —
+ * ger/model.py:216-259.  qkv: [n_tok, n_groups*(q_per_kv+2)*hs] in the group-interleaved layout
+ * [q0..q(q_per_kv-1) k v] per group (scripts/convert_hf_checkpoint.py:187-202).
+ *   q_out  [n_tok, n_head, hs]            rotated queries
+ *   k_cache [n_slots, n_groups, s_max, hs]   (compact GQA cache; the reference's 8x expansion
+ *   vT_cache[n_slots, n_groups, hs, s_max]    ger/model.py:225-227 is not materialised)
+ * tok_slot[t], tok_pos[t]: cache slot (sequence) and position of token t. */
+int dh_qkv_rope_cache_bf16(const dh_bf16* qkv, const dh_bf16* cos, const dh_bf16* sin,
+                           const int32_t* tok_slot, const int32_t* tok_pos, dh_bf16* q_out,
+                           dh_bf16* k_cache, dh_bf16* vT_cache, int n_tok, int n_head,
+                           int n_groups, int hs, int s_max, void* stream);
+
+/* ------------------------------------------------------------------ GEMMs (MFMA) */
+
+/* Epilogue selector for dh_linear_bf16 */
+#define DH_EPI_PLAIN   0   /* y = bf16(acc)                                 F.linear            */
+#define DH_EPI_LORA    1   /* y = bf16(bf16(acc) + bf16(bf16(lora_acc)*s))  ger/lora.py:159-166,388-402 */
+#define DH_EPI_SWIGLU  2   /* y = bf16(bf16(silu(bf16(acc1))) * bf16(acc2)) ger/model.py:313-315 */
+#define DH_EPI_ADAPTER 3   /* y = bf16(scale * bf16(bf16(acc) + bias))      ger/lora.py:70-71   */
+
+/* y[M,N] = epilogue(x[M,K] · W[N,K]^T).  K % 64 == 0, N % 8 == 0.
+ *  LORA   : xa [M, xa_ld] = bf16(x·A^T) (from dh_linear_bf16 PLAIN with W=A), lora_b [N,16]
+ *           (rank zero-padded to 16).  Output column n uses xa columns
+ *           [16*seg, 16*seg+16) with seg = (n >= split0) + (n >= split1): the contiguous
+ *           [Q|K|V] placement of ger/lora.py:226-234,343-347 (quirk Q2).  split0/1 % 32 == 0;
+ *           pass N,N for a single segment.
+ *  SWIGLU : w2 [N,K] second weight (fc_2); W is fc_1.
+ *  ADAPTER: vec_a = adapter_scale[N], vec_b = adapter_bias[N].
+ *  resid  : if non-NULL, y = bf16(resid + y_epilogue)  (residual add of ger/model.py:185-186)
+ *  M may be any value >= 1; for M <= 32 a weight-streaming kernel is used. */
+int dh_linear_bf16(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N, int K,
+                   int epilogue, const dh_bf16* w2, const dh_bf16* xa, int xa_ld,
+                   const dh_bf16* lora_b, float lora_scale, int split0, int split1,
+                   const dh_bf16* vec_a, const dh_bf16* vec_b, const dh_bf16* resid,
+                   void* stream);
+
+/* ------------------------------------------------------------------ attention */
+
+/* Causal attention of a packed batch against the KV cache — ger/model.py:261,270-290 with the
+ * boolean mask of ger/lora.py:530-531.  Sequence i owns q rows [q_start[i], q_start[i]+q_len[i])
+ * of q [n_tok, n_head, hs]; row j of it sits at position kv_pos0[i]+j and attends cache
+ * positions 0..kv_pos0[i]+j of slot seq_slot[i].  y: [n_tok, n_head*hs].  scale = 1/sqrt(hs). */
+int dh_attn_prefill_bf16(const dh_bf16* q, const dh_bf16* k_cache, const dh_bf16* vT_cache,
+                         const int32_t* seq_slot, const int32_t* q_start, const int32_t* q_len,
+                         const int32_t* kv_pos0, dh_bf16* y, int n_seq, int max_q_len,
+                         int n_head, int n_groups, int hs, int s_max, void* stream);
+
+/* One query token per sequence (decode step): q [n_seq, n_head, hs]; sequence i attends cache
+ * positions 0..kv_len[i]-1 of slot seq_slot[i].  work: >= dh_attn_decode_work_bytes(). */
+int64_t dh_attn_decode_work_bytes(int n_seq, int n_head, int hs, int s_max);
+int dh_attn_decode_bf16(const dh_bf16* q, const dh_bf16* k_cache, const dh_bf16* vT_cache,
+                        const int32_t* seq_slot, const int32_t* kv_len, dh_bf16* y, void* work,
+                        int n_seq, int n_head, int n_groups, int hs, int s_max, void* stream);
+
+/* ------------------------------------------------------------------ token sampling */
+
+/* One decode-loop tail per sequence — generate/base.py:62-80:
+ *   l = logits/temperature (bf16) ; keep l >= k-th largest ; softmax ; multinomial.
+ * top_k == 1 is resolved as arg-max with the LOWEST index among equal maxima (the reference
+ * breaks bf16 ties with the torch RNG, quirk Q6).  top_k == 0 means no cropping.  For
+ * top_k != 1 a counter hash of (seed, step, seq) drives the inverse-CDF draw.
+ *   tokens [n_seq, tok_ld] int64 : token buffer per sequence (prompt + generated)
+ *   length [n_seq] int32         : tokens currently valid; the new id goes to
+ *                                  tokens[i, length[i]] and length[i] is incremented
+ *   done   [n_seq] int32         : set to 1 when the new id == eos_id (eos_id < 0: never);
+ *                                  finished sequences are left untouched.
+ * No host synchronisation: the reference's per-token `if idx_next == eos_id`
+ * (generate/base.py:79) becomes the device-side flag. */
+int dh_sample_bf16(const dh_bf16* logits, int vocab, int64_t* tokens, int tok_ld, int32_t* length,
+                   int32_t* done, int n_seq, float temperature, int top_k, int64_t eos_id,
+                   uint64_t seed, int step, void* stream);
+
+/* ------------------------------------------------------------------ decoder engine
+ * Native runtime that owns the kernel sequence of ger/lora.py:504-549 for a whole batch:
+ * embed -> n_layer x [norm_1, qkv(+LoRA), rope+cache, attention, proj(+LoRA)+residual,
+ * norm_2, fc_1/fc_2+SwiGLU, proj+residual] -> ln_f -> lm_head, with the decode step captured
+ * in a hipGraph.  Weights are NOT copied: the table holds device pointers owned by the caller
+ * (the torch parameters of dualhyp_amd.GPT). */
+
+typedef struct dh_layer_weights {
+    const dh_bf16* norm_1;      /* [d]                                         */
+    const dh_bf16* norm_2;      /* [d]                                         */
+    const dh_bf16* attn_w;      /* [(n_head+2g)*hs, d]  attn.attn.linear.weight */
+    const dh_bf16* attn_lora_a; /* [48, d]  rank padded to 16 per q/k/v; NULL = no LoRA */
+    const dh_bf16* attn_lora_b; /* [(n_head+2g)*hs, 16]                        */
+    const dh_bf16* proj_w;      /* [d, d]               attn.proj.linear.weight */
+    const dh_bf16* proj_lora_a; /* [16, d] or NULL                             */
+    const dh_bf16* proj_lora_b; /* [d, 16]                                     */
+    const dh_bf16* fc_1;        /* [I, d]                                      */
+    const dh_bf16* fc_2;        /* [I, d]                                      */
+    const dh_bf16* mlp_proj;    /* [d, I]                                      */
+} dh_layer_weights;
+
+typedef struct dh_model_desc {
+    int32_t n_layer, n_head, n_groups, head_size, n_embd, intermediate, vocab, block_size;
+    float norm_eps;
+    float lora_scale;           /* alpha / r */
+    const dh_bf16* wte;         /* [vocab_rows, d] (vocab_rows >= vocab: RelPrompt adds rows) */
+    int32_t wte_rows;
+    const dh_bf16* ln_f;        /* [d] */
+    const dh_bf16* rope_cos;    /* [block_size, head_size] bf16 tables of ger/model.py:319-346 as built by */
+    const dh_bf16* rope_sin;    /*   GPT.build_rope_cache (base 10000, quirk Q1); made once by the host     */
+    const dh_bf16* lm_head;     /* [vocab, d] */
+    const dh_bf16* adapter_scale; /* [vocab] */
+    const dh_bf16* adapter_bias;  /* [vocab] */
+    const dh_layer_weights* h_layers; /* host array [n_layer] (copied) */
+} dh_model_desc;
+
+typedef struct dh_engine dh_engine;
+
+/* Allocates KV cache [n_layer][max_batch, g, s_max, hs] x2, activations for up to
+ * max_tokens packed tokens and the decode-graph state. */
+int dh_engine_create(const dh_model_desc* h_desc, int max_batch, int s_max, int max_tokens,
+                     dh_engine** h_out);
+void dh_engine_destroy(dh_engine* e);
+int64_t dh_engine_device_bytes(const dh_engine* e);
+
+/* Forward of a packed batch through the KV cache (ger/lora.py:504-549 with input_pos):
+ *   h_seq_len[i] tokens for slot i (i < n_seq) starting at cache position h_pos0[i];
+ *   ids: packed [sum(seq_len)] int64 on device.
+ * logits_all != NULL : [n_tok, vocab] logits of every position (reference behaviour, Q9)
+ * logits_last != NULL: [n_seq, vocab] logits of each sequence's last position only. */
+int dh_engine_forward(dh_engine* e, const int64_t* ids, const int32_t* h_seq_len,
+                      const int32_t* h_pos0, int n_seq, dh_bf16* logits_all,
+                      dh_bf16* logits_last, void* stream);
+
+/* The decode loop of generate/base.py:57-80 for n_seq sequences at once, entirely on device:
+ * tokens [n_seq, tok_ld] holds the prompts (length[i] valid ids each, already prefilled
+ * through position length[i]-2; the last prompt token's logits are `logits_last` of the
+ * prefill and must have been sampled already, i.e. length includes the first new token).
+ * Runs `n_steps` x { forward(one token/seq at position length-1) ; sample }.  Sequences with
+ * done[i] != 0 keep stepping harmlessly but their tokens/length are frozen. */
+int dh_engine_decode(dh_engine* e, int64_t* tokens, int tok_ld, int32_t* length, int32_t* done,
+                     int n_seq, int n_steps, float temperature, int top_k, int64_t eos_id,
+                     uint64_t seed, int first_step, void* stream);
+
+/* Test hook: copy engine state to `dst` (device memory, n_bytes) on `stream`.
+ *   what 0: ln_f(x) of the last dh_engine_forward called with logits_all only, [n_tok, d]
+ *   what 1: K   cache of `layer`  [max_batch, g, s_max, hs]
+ *   what 2: V^T cache of `layer`  [max_batch, g, hs, s_max]
+ *   what 3: residual stream x after the last layer of the last forward, [n_tok, d] */
+int dh_engine_read(dh_engine* e, int what, int layer, void* dst, int64_t n_bytes, void* stream);
+/* HIP-event timing of the dominant kernels inside the last forward/decode call (bench.py
+ * roofline): returns accumulated milliseconds and launch count for kernel class `which`
+ * (0 = prefill GEMM, 1 = decode weight-streaming GEMM, 2 = prefill attention,
+ *  3 = decode attention); enable with dh_engine_set_timing(e, 1). */
+int dh_engine_set_timing(dh_engine* e, int on);
+int dh_engine_get_timing(dh_engine* e, int which, double* h_ms, int64_t* h_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DUALHYP_HIP_H */

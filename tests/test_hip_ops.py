@@ -1,0 +1,239 @@
+"""GPU parity of each HIP kernel against the oracle's op on the same seeded inputs, through the
+C ABI (dualhyp_amd.ops -> libdualhyp_hip.so).  Tolerances are in bf16 ulps: the kernels round
+at the reference's rounding points, so differences can only come from fp32 summation order
+(a result landing on the other side of a bf16 rounding boundary)."""
+import math
+
+import pytest
+import torch
+
+from conftest import ulp_diff
+from dualhyp_amd.synth import uniform, stream_id
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def U(shape, bound, name, seed=11):
+    return uniform(shape, bound, stream_id(seed, name))
+
+
+def check_ulp(got, want, max_ulp, max_frac, what):
+    u = ulp_diff(got.float().cpu(), want.float())
+    frac = (u > 0).float().mean().item()
+    assert u.max().item() <= max_ulp and frac <= max_frac, f"{what}: max {u.max().item():.2f} ulp, {frac:.3%} of elements differ"
+    return u.max().item(), frac
+
+
+@pytest.mark.parametrize("rows,d", [(37, 2048), (5, 256), (3, 4096), (64, 512)])
+def test_rmsnorm(dev, rows, d):
+    from dualhyp_amd import ops
+    from oracle import ger_oracle as O
+    x = U((rows, d), 2.0, f"x{d}")
+    w = (1 + U((d,), 0.25, f"w{d}").float()).bfloat16()
+    got = ops.rmsnorm(x.to(dev), w.to(dev), 1e-5)
+    check_ulp(got, O.rmsnorm(x, w, 1e-5), 1, 0.02, "rmsnorm")
+    r = U((rows, d), 1.0, f"r{d}")
+    got, s = ops.rmsnorm(x.to(dev), w.to(dev), 1e-5, resid=r.to(dev), return_sum=True)
+    assert torch.equal(s.cpu(), x + r)
+    check_ulp(got, O.rmsnorm(x + r, w, 1e-5), 1, 0.02, "add+rmsnorm")
+
+
+def test_embed(dev):
+    from dualhyp_amd import ops
+    wte = U((300, 256), 1.0, "wte")
+    ids = torch.tensor([0, 5, 299, 7, 7, 123], dtype=torch.int64)
+    assert torch.equal(ops.embed(ids.to(dev), wte.to(dev)).cpu(), wte[ids])
+
+
+@pytest.mark.parametrize("M,N,K", [(100, 384, 256), (1, 128, 64), (257, 2560, 2048), (33, 136, 128), (640, 256, 5632)])
+def test_linear_plain_and_resid(dev, M, N, K):
+    from dualhyp_amd import ops
+    x, w = U((M, K), 1.0, "lx"), U((N, K), 0.05, "lw")
+    want = torch.nn.functional.linear(x, w)
+    check_ulp(ops.linear(x.to(dev), w.to(dev)), want, 1, 0.02, "linear")
+    r = U((M, N), 1.0, "lr")
+    check_ulp(ops.linear(x.to(dev), w.to(dev), resid=r.to(dev)), r + want, 1, 0.02, "linear+resid")
+
+
+@pytest.mark.parametrize("M,d,r", [(70, 256, 4), (130, 2048, 16)])
+def test_linear_lora(dev, M, d, r):
+    """ger/lora.py:159-166 (proj) and :367-402 (qkv, contiguous [Q|K|V] delta, quirk Q2)."""
+    from dualhyp_amd import ops
+    from dualhyp_amd.gpt import _pad_rank
+    from oracle import ger_oracle as O
+    kv = d // 2
+    N = d + 2 * kv
+    x = U((1, M, d), 1.0, "qx")
+    W = U((N, d), 0.05, "qw")
+    A = U((3 * r, d), 1 / math.sqrt(d), "qa")
+    B = U((N, r), 0.05, "qb")
+    s = 2.0
+    want = O.lora_qkv_linear(x, W, A, B, s, (d, kv, kv))
+    A48 = torch.zeros(48, d, dtype=torch.bfloat16)
+    for seg in range(3):
+        A48[16 * seg:16 * seg + r] = A[seg * r:(seg + 1) * r]
+    B16 = _pad_rank(B, r, 1)
+    xd = x.to(dev)
+    xa = ops.linear(xd, A48.to(dev))
+    got = ops.linear(xd, W.to(dev), epilogue=ops.EPI_LORA, xa=xa, lora_b=B16.to(dev), lora_scale=s, splits=(d, d + kv))
+    check_ulp(got, want, 1, 0.02, "qkv lora")
+    # single-segment (attn.proj) with fused residual
+    Wp, Ap, Bp = U((d, d), 0.05, "pw"), U((r, d), 1 / math.sqrt(d), "pa"), U((d, r), 0.05, "pb")
+    res = U((1, M, d), 1.0, "pr")
+    want = res + O.lora_linear(x, Wp, Ap, Bp, s)
+    xa = ops.linear(xd, _pad_rank(Ap, r, 0).to(dev))
+    got = ops.linear(xd, Wp.to(dev), epilogue=ops.EPI_LORA, xa=xa, lora_b=_pad_rank(Bp, r, 1).to(dev), lora_scale=s,
+                     resid=res.to(dev))
+    check_ulp(got, want, 1, 0.02, "proj lora + resid")
+
+
+@pytest.mark.parametrize("M,d,I", [(50, 256, 384), (200, 2048, 5632)])
+def test_linear_swiglu_and_adapter(dev, M, d, I):
+    from dualhyp_amd import ops
+    x, w1, w2 = U((M, d), 1.0, "sx"), U((I, d), 0.05, "s1"), U((I, d), 0.05, "s2")
+    F = torch.nn.functional
+    want = F.silu(F.linear(x, w1)) * F.linear(x, w2)
+    check_ulp(ops.linear(x.to(dev), w1.to(dev), epilogue=ops.EPI_SWIGLU, w2=w2.to(dev)), want, 1, 0.03, "swiglu")
+    sc = (1 + U((I,), 0.5, "sc").float()).bfloat16()
+    bi = U((I,), 0.5, "bi")
+    want = sc * (F.linear(x, w1) + bi)
+    check_ulp(ops.linear(x.to(dev), w1.to(dev), epilogue=ops.EPI_ADAPTER, scale=sc.to(dev), bias=bi.to(dev)), want,
+              1, 0.02, "adapter")
+
+
+def _attn_setup(dev, hs, n_head, n_groups, lens, pos0, s_max, seed):
+    """Random qkv for a ragged batch -> (ops outputs, oracle-side q/k/v per sequence)."""
+    from dualhyp_amd import ops
+    from oracle import ger_oracle as O
+    qpk = n_head // n_groups
+    width = (n_head + 2 * n_groups) * hs
+    n_tok = sum(lens)
+    qkv = U((n_tok, width), 1.0, f"aqkv{seed}")
+    cos, sin = O.build_rope_cache(s_max, hs)
+    slot = torch.cat([torch.full((n,), i, dtype=torch.int32) for i, n in enumerate(lens)])
+    pos = torch.cat([torch.arange(p, p + n, dtype=torch.int32) for p, n in zip(pos0, lens)])
+    B = len(lens)
+    kc = torch.zeros((B, n_groups, s_max, hs), dtype=torch.bfloat16, device=dev)
+    vt = torch.zeros((B, n_groups, hs, s_max), dtype=torch.bfloat16, device=dev)
+    q = ops.qkv_rope_cache(qkv.to(dev), cos.to(dev), sin.to(dev), slot.to(dev), pos.to(dev), kc, vt, n_head, n_groups)
+    # oracle split/rope per sequence (ger/model.py:216-246)
+    ref = []
+    t0 = 0
+    for n, p in zip(lens, pos0):
+        x = qkv[t0:t0 + n].view(1, n, n_groups, qpk + 2, hs).permute(0, 2, 3, 1, 4)
+        qq, kk, vv = x.split((qpk, 1, 1), dim=2)
+        qq = qq.reshape(1, -1, n, hs)
+        kk = kk.reshape(1, -1, n, hs)
+        vv = vv.reshape(1, -1, n, hs)
+        c, s = cos[p:p + n], sin[p:p + n]
+        ref.append((O.apply_rope(qq, c, s), O.apply_rope(kk, c, s), vv))
+        t0 += n
+    return q, kc, vt, ref
+
+
+@pytest.mark.parametrize("hs,n_head,n_groups", [(64, 32, 4), (64, 4, 2), (128, 8, 2)])
+def test_qkv_rope_cache_and_prefill_attention(dev, hs, n_head, n_groups):
+    from dualhyp_amd import ops
+    lens, pos0, s_max = [70, 1, 33, 128], [0, 0, 0, 0], 192
+    q, kc, vt, ref = _attn_setup(dev, hs, n_head, n_groups, lens, pos0, s_max, seed=hs + n_head)
+    qpk = n_head // n_groups
+    t0 = 0
+    for i, (n, (rq, rk, rv)) in enumerate(zip(lens, ref)):
+        assert torch.equal(q[t0:t0 + n].cpu().permute(1, 0, 2), rq[0]), "rotated q"
+        assert torch.equal(kc[i, :, :n].cpu(), rk[0]), "k cache"
+        assert torch.equal(vt[i, :, :, :n].cpu().transpose(1, 2), rv[0]), "v^T cache"
+        t0 += n
+    i32 = torch.int32
+    starts = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)[:-1]), dtype=i32)
+    y = ops.attn_prefill(q, kc, vt, torch.arange(len(lens), dtype=i32).to(dev), starts.to(dev),
+                         torch.tensor(lens, dtype=i32).to(dev), torch.tensor(pos0, dtype=i32).to(dev), max(lens))
+    t0 = 0
+    worst = 0.0
+    for n, (rq, rk, rv) in zip(lens, ref):
+        k = rk.repeat_interleave(qpk, dim=1)
+        v = rv.repeat_interleave(qpk, dim=1)
+        want = torch.nn.functional.scaled_dot_product_attention(rq, k, v, is_causal=True, scale=1 / math.sqrt(hs))
+        want = want.transpose(1, 2).reshape(n, n_head * hs)
+        # fp32 ground truth decides what "close" means: both are roundings of it
+        truth = torch.nn.functional.scaled_dot_product_attention(rq.float(), k.float(), v.float(), is_causal=True,
+                                                                 scale=1 / math.sqrt(hs)).transpose(1, 2).reshape(n, -1)
+        got = y[t0:t0 + n].float().cpu()
+        err_hip = (got - truth).abs().max().item()
+        err_ref = (want.float() - truth).abs().max().item()
+        assert err_hip <= max(2 * err_ref, 2e-2), f"prefill attention: hip err {err_hip} vs reference-kernel err {err_ref}"
+        u = ulp_diff(got, want.float())
+        worst = max(worst, u.max().item())
+        assert u.max().item() <= 4 and (u > 1).float().mean().item() < 0.01, f"{u.max().item()} ulp"
+        t0 += n
+
+
+@pytest.mark.parametrize("hs,n_head,n_groups", [(64, 32, 4), (128, 8, 2)])
+def test_chunked_prefill_and_decode_attention(dev, hs, n_head, n_groups):
+    """Prefill T-1 tokens, then one decode token per sequence at ragged positions; the decode
+    kernel must agree with the prefill kernel run on the same cache and with fp32 attention."""
+    from dualhyp_amd import ops
+    lens, s_max = [100, 37, 64, 1, 129], 192
+    q, kc, vt, ref = _attn_setup(dev, hs, n_head, n_groups, lens, [0] * len(lens), s_max, seed=3)
+    qpk = n_head // n_groups
+    i32 = torch.int32
+    ends = torch.tensor(lens).cumsum(0)
+    last_rows = (ends - 1).tolist()
+    qd = q[last_rows].contiguous()                       # the last token of each sequence as a decode query
+    kv_len = torch.tensor(lens, dtype=i32).to(dev)
+    y = ops.attn_decode(qd, kc, vt, torch.arange(len(lens), dtype=i32).to(dev), kv_len)
+    for i, (n, (rq, rk, rv)) in enumerate(zip(lens, ref)):
+        k = rk.repeat_interleave(qpk, dim=1).float()
+        v = rv.repeat_interleave(qpk, dim=1).float()
+        truth = torch.nn.functional.scaled_dot_product_attention(rq[:, :, -1:].float(), k, v, scale=1 / math.sqrt(hs))
+        truth = truth.transpose(1, 2).reshape(-1)
+        err = (y[i].float().cpu() - truth).abs().max().item()
+        assert err <= 2e-2, f"decode attention seq {i}: err {err}"
+
+
+def test_sampling_argmax_ties_and_eos(dev):
+    """generate/base.py:62-80 tail: lowest-index arg-max after the bf16 temperature divide
+    (Q6), EOS flag (Q7), frozen finished sequences."""
+    from dualhyp_amd import ops
+    V = 32000
+    lg = U((4, V), 3.0, "slog")
+    lg[0, 777] = 9.0
+    lg[0, 31999] = 9.0          # exact tie -> lowest index
+    lg[1, 5] = 8.0
+    lg[2, V - 1] = 8.5
+    lg[3, 100] = 7.0
+    tokens = torch.zeros((4, 8), dtype=torch.int64, device=dev)
+    length = torch.tensor([3, 1, 2, 4], dtype=torch.int32, device=dev)
+    done = torch.tensor([0, 0, 0, 1], dtype=torch.int32, device=dev)
+    ops.sample(lg.to(dev), tokens, length, done, temperature=0.2, top_k=1, eos_id=5)
+    assert tokens.cpu()[0, 3] == 777 and tokens.cpu()[1, 1] == 5 and tokens.cpu()[2, 2] == V - 1
+    assert length.tolist() == [4, 2, 3, 4] and done.tolist() == [0, 1, 0, 1]
+    # ties created by the bf16 rounding of logit/temperature
+    row = torch.zeros(V, dtype=torch.bfloat16)
+    row[10], row[20] = 1.0, 1.0039062   # distinct logits ...
+    want = int(torch.nonzero((row / 0.2) == (row / 0.2).max())[0])
+    tokens.zero_(); length.fill_(0); done.zero_()
+    ops.sample(row.view(1, -1).repeat(4, 1).to(dev), tokens, length, done, temperature=0.2, top_k=1)
+    assert tokens[0, 0].item() == want
+
+
+def test_sampling_topk_distribution(dev):
+    from dualhyp_amd import ops
+    V, k, n = 1000, 5, 4096
+    base = torch.full((V,), -2.0)
+    base[[3, 50, 400, 800, 999]] = torch.tensor([2.0, 1.5, 1.0, 0.5, 0.0])
+    lg = base.bfloat16().view(1, -1).repeat(n, 1).to(dev)
+    tokens = torch.zeros((n, 1), dtype=torch.int64, device=dev)
+    length = torch.zeros(n, dtype=torch.int32, device=dev)
+    done = torch.zeros(n, dtype=torch.int32, device=dev)
+    ops.sample(lg, tokens, length, done, temperature=1.0, top_k=k, seed=99, step=0)
+    picks = tokens.view(-1).cpu()
+    assert set(picks.tolist()) <= {3, 50, 400, 800, 999}
+    p = torch.softmax(torch.tensor([2.0, 1.5, 1.0, 0.5, 0.0]), 0)
+    freq = torch.tensor([(picks == t).float().mean() for t in (3, 50, 400, 800, 999)])
+    assert (freq - p).abs().max() < 0.03, (freq, p)
