@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""Headline benchmark: corrected utterances/s of the DualHyp decoder on MI355X.
+
+Workload (BASELINE.json configs[1]): TinyLlama-1.1B + LoRA r=16 on q,k,v,proj, bf16, batch of
+32 synthetic 5+5-hypothesis prompts of 512 tokens per GPU, 64 generated tokens each
+(eos disabled so exactly 64 are produced), greedy (top_k=1, temperature 0.2) — one "step" is
+one such batch through packed prefill + 63 hipGraph decode steps.  Weights are random-init of
+the TinyLlama architecture from a counter hash (no checkpoints offline); prompts are
+token-id level (no tokenizer offline).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Data-parallel replicas: every rank decodes its own batch, no collective in the data path
+(SURVEY.md §8e); value = utterances of all ranks / max-over-ranks time.  Rank 0 prints ONE JSON
+line with the `roofline` of the dominant kernel class (prefill MFMA GEMMs, timed live with HIP
+events on the launch stream) and, at N=1, the `cpu_baseline` (the oracle = CPU restatement of
+the reference, timed on this host's cores on one utterance of the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+
+PROMPT_LEN, NEW_TOKENS, BATCH = 512, 64, 32
+MFMA_PEAK_TFLOPS = 2500.0     # bf16 dense, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def gemm_flops_per_prefill(cfg, n_tok: int, n_seq: int) -> float:
+    """Algorithmic FLOPs of the M>32 GEMM launches of one packed prefill:
+    per layer qkv + proj + fc_1 + fc_2 + mlp proj on every token; LoRA rank-16 side products;
+    the lm_head runs on the last position only (M = n_seq <= 32: not in this class)."""
+    d, I = cfg.n_embd, cfg.intermediate_size
+    qkv = (cfg.n_head + 2 * cfg.n_query_groups) * cfg.head_size
+    per_tok = 2 * d * (qkv + d + 3 * I)
+    lora = 2 * d * (48 + 16) + 2 * 16 * (qkv + d)
+    return float(cfg.n_layer * n_tok * (per_tok + lora))
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    from dualhyp_amd import GPT, Config, GER_LORA, generate_batch
+    from dualhyp_amd.synth import synth_state_dict, synth_prompts
+
+    cfg = Config.from_name("tiny-llama-1.1b-chat", **{**GER_LORA, "dropout": 0.0})
+    sd = synth_state_dict(cfg, seed=1337, device=dev)
+    model = GPT(cfg).to(device=dev, dtype=torch.bfloat16)
+    model.load_state_dict(sd, strict=True)
+    del sd
+    model.eval()
+    B = a.batch
+    model.set_capacity(B, PROMPT_LEN + NEW_TOKENS, B * PROMPT_LEN)
+    # every rank gets its own utterances (strided shard of one synthetic corpus)
+    n_batches = a.steps + a.warmup
+    corpus = synth_prompts(B * n_batches * world, PROMPT_LEN, cfg.padded_vocab_size, seed=1337)
+    mine = [p.to(dev) for p in corpus[rank::world]]
+
+    def step(i: int):
+        return generate_batch(model, mine[i * B:(i + 1) * B], NEW_TOKENS, temperature=0.2, top_k=1, eos_id=None)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    eng = model.engine()
+    eng.set_timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        out = step(a.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    gemm_ms, gemm_n = eng.get_timing(0)
+    attn_ms, attn_n = eng.get_timing(2)
+    eng.set_timing(False)
+    assert all(o.numel() == PROMPT_LEN + NEW_TOKENS for o in out)
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    result = None
+    if rank == 0:
+        utt = B * a.steps * world
+        flops = gemm_flops_per_prefill(cfg, B * PROMPT_LEN, B) * a.steps
+        achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        result = {
+            "metric": "corrected utterances/sec (TinyLlama-1.1B, 5+5 hyps, 512->64 tok)",
+            "value": utt / dt, "unit": "utterances/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "DualHyp inference, TinyLlama-1.1B bf16 + LoRA r16 (q,k,v,proj), batch 32/GPU "
+                                   "synthetic 5+5-hyp prompts, 512-token prompt -> 64 generated tokens, greedy",
+                       "batch_per_gpu": B, "prompt_tokens": PROMPT_LEN, "new_tokens": NEW_TOKENS,
+                       "parallelism": f"replicas x{world}"},
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (prefill GEMMs: qkv+LoRA, proj+LoRA, fc_1/fc_2 SwiGLU, mlp proj)",
+                         "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None,
+                         "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
+                         "prefill_attention_ms_per_step": attn_ms / max(a.steps, 1)},
+        }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(cfg, corpus[0], NEW_TOKENS)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cfg, prompt, new_tokens: int) -> dict:
+    """The oracle (CPU restatement of ger/lora.py + generate/base.py, pinned to the reference by
+    tests/golden) timed on this host: ONE utterance of the same workload, batch 1 as the
+    reference runs it (inference/ger.py:60-81)."""
+    from dualhyp_amd.synth import synth_state_dict
+    from oracle import ger_oracle as O
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))   # the box's CPU share for one GPU
+    sd = synth_state_dict(cfg, seed=1337, device="cpu")
+    m = O.OracleGPT(cfg, sd)
+    T = prompt.numel()
+    t0 = time.perf_counter()
+    ids = O.generate(m, prompt.cpu(), T + new_tokens, temperature=0.2, top_k=1, eos_id=None, mode="argmax")
+    dt = time.perf_counter() - t0
+    assert ids.numel() == T + new_tokens
+    return {"value": 1.0 / dt, "unit": "utterances/s",
+            "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 utterance, {T}-token prompt -> {new_tokens} generated tokens, batch 1, bf16, "
+                      f"{torch.get_num_threads()} threads ({dt:.1f} s)"}
+
+
+if __name__ == "__main__":
+    main()

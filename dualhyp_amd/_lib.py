@@ -36,7 +36,7 @@ SIGNATURES = {
     "dh_last_error": (C.c_char_p, []),
     "dh_device_info": (I, [C.c_char_p, I, C.POINTER(I), C.POINTER(I64)]),
     "dh_embed_bf16": (I, [P, P, P, I, I, I, P]),
-    "dh_rmsnorm_bf16": (I, [P, P, P, P, P, I, I, F, P]),
+    "dh_rmsnorm_bf16": (I, [P, P, P, P, P, I, I, F, P, P]),
     "dh_qkv_rope_cache_bf16": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "dh_linear_bf16": (I, [P, P, P, I, I, I, I, P, P, I, P, F, I, I, P, P, P, P]),
     "dh_attn_prefill_bf16": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
@@ -47,6 +47,7 @@ SIGNATURES = {
     "dh_engine_destroy": (None, [P]),
     "dh_engine_device_bytes": (I64, [P]),
     "dh_engine_forward": (I, [P, P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), I, P, P, P]),
+    "dh_engine_set_cpu_rsqrt_emulation": (I, [P, I, I]),
     "dh_engine_decode": (I, [P, P, I, P, P, I, I, F, I, I64, U64, I, P]),
     "dh_engine_read": (I, [P, I, I, P, I64, P]),
     "dh_engine_set_timing": (I, [P, I]),

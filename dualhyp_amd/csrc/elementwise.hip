@@ -37,7 +37,8 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__
                                                       const bf16_t* __restrict__ resid,
                                                       const bf16_t* __restrict__ w,
                                                       bf16_t* __restrict__ out,
-                                                      bf16_t* __restrict__ sum_out, int rows, int d, float eps) {
+                                                      bf16_t* __restrict__ sum_out, int rows, int d, float eps,
+                                                      const uint8_t* __restrict__ row_tail) {
     const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -72,7 +73,10 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__
     }
     ss = wave_sum(ss);
     const float ms = rbf(ss / (float)d);           // fp32 sum / d, ONE rounding (verified vs torch CPU)
-    const float r = rbf(1.0f / sqrtf(rbf(ms + eps)));
+    const float t = rbf(ms + eps);
+    // torch's CPU bf16 rsqrt: vector loop = one rounding; scalar tail loop rounds sqrt(t) first (Q11)
+    const bool tail = row_tail != nullptr && row_tail[row] != 0;
+    const float r = tail ? rbf(1.0f / rbf(sqrtf(t))) : rbf(1.0f / sqrtf(t));
     const uint4* wr = reinterpret_cast<const uint4*>(w);
     uint4* orow = reinterpret_cast<uint4*>(out + (size_t)row * d);
 #pragma unroll
@@ -91,16 +95,17 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__
 }
 
 extern "C" int dh_rmsnorm_bf16(const dh_bf16* x, const dh_bf16* resid, const dh_bf16* w, dh_bf16* out,
-                               dh_bf16* sum_out, int rows, int d, float eps, void* stream) {
+                               dh_bf16* sum_out, int rows, int d, float eps, const uint8_t* row_tail,
+                               void* stream) {
     DH_CHECK(rows >= 0 && d > 0 && d % 8 == 0 && d <= 8192, "dh_rmsnorm_bf16: unsupported d=%d (need d%%8==0, d<=8192)", d);
     if (rows == 0) return 0;
     dim3 grid(cdiv(rows, 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH(MAXC)                                                                                   \
     if (resid)                                                                                         \
-        hipLaunchKernelGGL((rmsnorm_kernel<MAXC, true>), grid, block, 0, s, x, resid, w, out, sum_out, rows, d, eps); \
+        hipLaunchKernelGGL((rmsnorm_kernel<MAXC, true>), grid, block, 0, s, x, resid, w, out, sum_out, rows, d, eps, row_tail); \
     else                                                                                               \
-        hipLaunchKernelGGL((rmsnorm_kernel<MAXC, false>), grid, block, 0, s, x, resid, w, out, sum_out, rows, d, eps)
+        hipLaunchKernelGGL((rmsnorm_kernel<MAXC, false>), grid, block, 0, s, x, resid, w, out, sum_out, rows, d, eps, row_tail)
     if (d <= 512) { LAUNCH(1); }
     else if (d <= 2048) { LAUNCH(4); }
     else if (d <= 4096) { LAUNCH(8); }

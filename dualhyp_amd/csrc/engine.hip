@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "common.h"
+#include "gemm.h"
 
 int dh_sample_impl(const dh_bf16* logits, int vocab, int64_t* tokens, int tok_ld, int32_t* length, int32_t* done,
                    int n_seq, float temperature, int top_k, int64_t eos_id, uint64_t seed, int step,
@@ -31,6 +32,8 @@ struct dh_engine {
            *act = nullptr, *xlast = nullptr, *logits = nullptr;
     int32_t *tok_slot = nullptr, *tok_pos = nullptr, *seq_meta = nullptr;   // seq_meta: 4 x [B]
     int32_t *last_row = nullptr, *step_dev = nullptr;
+    uint8_t *row_tail = nullptr, *last_tail = nullptr, *ones = nullptr;   // Q11 rsqrt emulation flags
+    int rsqrt_vec = 0, rsqrt_whole = 0;
     int64_t* dec_ids = nullptr;
     void* dec_work = nullptr;
     int32_t* h_stage = nullptr;                         // pinned staging for the metadata
@@ -42,6 +45,8 @@ struct dh_engine {
     hipGraphExec_t gexec = nullptr;
     struct { int64_t* tokens; int tok_ld; int32_t *length, *done; int n_seq, top_k; float temp; int64_t eos; uint64_t seed; } gkey{};
     int last_ntok = 0;
+    bool capturing = false;   // no event records inside a stream capture
+    bool phase_decode = false; // single-token-per-sequence call: weight-streaming GEMMs + split-KV attention
     Timing tm;
 };
 
@@ -83,7 +88,7 @@ __global__ void gather_rows_kernel(const bf16_t* __restrict__ src, const int32_t
 struct TimeScope {
     dh_engine* e; int which; hipStream_t s; hipEvent_t a = nullptr, b = nullptr;
     TimeScope(dh_engine* e_, int w, hipStream_t s_) : e(e_), which(w), s(s_) {
-        if (!e->tm.on) return;
+        if (!e->tm.on || e->capturing) return;
         hipEventCreate(&a); hipEventCreate(&b);
         hipEventRecord(a, s);
     }
@@ -97,16 +102,21 @@ struct TimeScope {
 int linear(dh_engine* e, const bf16_t* x, const bf16_t* w, bf16_t* y, int M, int N, int K, int epi,
            const bf16_t* w2, const bf16_t* xa, int xa_ld, const bf16_t* lb, int s0, int s1, const bf16_t* va,
            const bf16_t* vb, const bf16_t* resid, hipStream_t s, bool timed) {
+    // kernel choice is a property of the phase, never of the packing (batch invariance)
+    const int kernel = e->phase_decode ? 0 : 1;
     if (timed) {
-        TimeScope t(e, M <= 32 ? 1 : 0, s);
-        return dh_linear_bf16(x, w, y, M, N, K, epi, w2, xa, xa_ld, lb, e->d.lora_scale, s0, s1, va, vb, resid, s);
+        TimeScope t(e, e->phase_decode ? 1 : 0, s);
+        return dh_linear_impl(x, w, y, M, N, K, epi, w2, xa, xa_ld, lb, e->d.lora_scale, s0, s1, va, vb, resid, kernel, s);
     }
-    return dh_linear_bf16(x, w, y, M, N, K, epi, w2, xa, xa_ld, lb, e->d.lora_scale, s0, s1, va, vb, resid, s);
+    return dh_linear_impl(x, w, y, M, N, K, epi, w2, xa, xa_ld, lb, e->d.lora_scale, s0, s1, va, vb, resid, kernel, s);
 }
 
 // The layer stack on n_tok packed tokens whose metadata is already on the device.
 // prefill: attention over (seq_slot, q_start, q_len, kv_pos0); decode: one token per sequence.
-int run_layers(dh_engine* e, const int64_t* ids, int n_tok, int n_seq, int max_q_len, bool decode, hipStream_t s) {
+int run_layers(dh_engine* e, const int64_t* ids, int n_tok, int n_seq, int max_q_len, bool decode,
+               const uint8_t* tail_flags, hipStream_t s) {
+    const uint8_t* rt = e->rsqrt_vec > 0 ? tail_flags : nullptr;
+    e->phase_decode = decode;
     const dh_model_desc& D = e->d;
     const int d = D.n_embd, I = D.intermediate, hs = D.head_size, H = D.n_head, G = D.n_groups;
     int32_t* seq_slot = e->seq_meta;
@@ -119,7 +129,7 @@ int run_layers(dh_engine* e, const int64_t* ids, int n_tok, int n_seq, int max_q
         const dh_layer_weights& W = e->layers[l];
         bf16_t* kc = e->kc + (size_t)l * e->cache_layer_elems;
         bf16_t* vtc = e->vtc + (size_t)l * e->cache_layer_elems;
-        if ((rc = dh_rmsnorm_bf16(e->x, nullptr, W.norm_1, e->xn, nullptr, n_tok, d, D.norm_eps, s))) return rc;
+        if ((rc = dh_rmsnorm_bf16(e->x, nullptr, W.norm_1, e->xn, nullptr, n_tok, d, D.norm_eps, rt, s))) return rc;
         if (W.attn_lora_a) {
             if ((rc = linear(e, e->xn, W.attn_lora_a, e->xa, n_tok, 48, d, DH_EPI_PLAIN, nullptr, nullptr, 0, nullptr, 0, 0,
                              nullptr, nullptr, nullptr, s, false))) return rc;
@@ -149,7 +159,7 @@ int run_layers(dh_engine* e, const int64_t* ids, int n_tok, int n_seq, int max_q
             if ((rc = linear(e, e->att, W.proj_w, e->x, n_tok, d, d, DH_EPI_PLAIN, nullptr, nullptr, 0, nullptr, 0, 0,
                              nullptr, nullptr, e->x, s, true))) return rc;
         }
-        if ((rc = dh_rmsnorm_bf16(e->x, nullptr, W.norm_2, e->xn, nullptr, n_tok, d, D.norm_eps, s))) return rc;
+        if ((rc = dh_rmsnorm_bf16(e->x, nullptr, W.norm_2, e->xn, nullptr, n_tok, d, D.norm_eps, rt, s))) return rc;
         if ((rc = linear(e, e->xn, W.fc_1, e->act, n_tok, I, d, DH_EPI_SWIGLU, W.fc_2, nullptr, 0, nullptr, 0, 0, nullptr,
                          nullptr, nullptr, s, true))) return rc;
         if ((rc = linear(e, e->act, W.mlp_proj, e->x, n_tok, d, I, DH_EPI_PLAIN, nullptr, nullptr, 0, nullptr, 0, 0, nullptr,
@@ -158,10 +168,11 @@ int run_layers(dh_engine* e, const int64_t* ids, int n_tok, int n_seq, int max_q
     return 0;
 }
 
-int head(dh_engine* e, const bf16_t* xrows, int rows, bf16_t* logits, hipStream_t s) {
+int head(dh_engine* e, const bf16_t* xrows, int rows, bf16_t* logits, const uint8_t* rt, hipStream_t s) {
     const dh_model_desc& D = e->d;
     int rc;
-    if ((rc = dh_rmsnorm_bf16(xrows, nullptr, D.ln_f, e->xn, nullptr, rows, D.n_embd, D.norm_eps, s))) return rc;
+    if ((rc = dh_rmsnorm_bf16(xrows, nullptr, D.ln_f, e->xn, nullptr, rows, D.n_embd, D.norm_eps,
+                              e->rsqrt_vec > 0 ? rt : nullptr, s))) return rc;
     return linear(e, e->xn, D.lm_head, logits, rows, D.vocab, D.n_embd, DH_EPI_ADAPTER, nullptr, nullptr, 0, nullptr, 0, 0,
                   D.adapter_scale, D.adapter_bias, nullptr, s, true);
 }
@@ -208,6 +219,9 @@ extern "C" int dh_engine_create(const dh_model_desc* desc, int max_batch, int s_
     rc |= dmalloc(e, &e->last_row, (size_t)max_batch);
     rc |= dmalloc(e, &e->step_dev, 1);
     rc |= dmalloc(e, &e->dec_ids, (size_t)max_batch);
+    rc |= dmalloc(e, &e->row_tail, T);
+    rc |= dmalloc(e, &e->last_tail, (size_t)max_batch);
+    rc |= dmalloc(e, &e->ones, (size_t)max_batch);
     const int64_t wb = dh_attn_decode_work_bytes(max_batch, H, hs, s_max);
     if (!rc) { hipError_t he = hipMalloc(&e->dec_work, wb); if (he != hipSuccess) rc = 2; e->dev_bytes += wb; }
     if (rc) { dh_set_error("dh_engine_create: device allocation failed (%s)", dh_last_error()); dh_engine_destroy(e); return 2; }
@@ -215,7 +229,8 @@ extern "C" int dh_engine_create(const dh_model_desc* desc, int max_batch, int s_
     DH_HIP(hipMemset(e->kc, 0, e->cache_layer_elems * desc->n_layer * sizeof(bf16_t)));
     DH_HIP(hipMemset(e->vtc, 0, e->cache_layer_elems * desc->n_layer * sizeof(bf16_t)));
     DH_HIP(hipMemset(e->step_dev, 0, sizeof(int32_t)));
-    DH_HIP(hipHostMalloc((void**)&e->h_stage, (2 * T + 5 * (size_t)max_batch) * sizeof(int32_t)));
+    DH_HIP(hipMemset(e->ones, 1, (size_t)max_batch));
+    DH_HIP(hipHostMalloc((void**)&e->h_stage, (3 * T + 6 * (size_t)max_batch) * sizeof(int32_t)));
     DH_HIP(hipStreamCreateWithFlags(&e->gstream, hipStreamNonBlocking));
     DH_HIP(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
     DH_HIP(hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming));
@@ -227,7 +242,8 @@ extern "C" void dh_engine_destroy(dh_engine* e) {
     if (!e) return;
     if (e->gexec) hipGraphExecDestroy(e->gexec);
     void* ptrs[] = {e->kc, e->vtc, e->x, e->xn, e->qkv, e->qrot, e->att, e->xa, e->act, e->xlast, e->logits,
-                    e->tok_slot, e->tok_pos, e->seq_meta, e->last_row, e->step_dev, e->dec_ids, e->dec_work};
+                    e->tok_slot, e->tok_pos, e->seq_meta, e->last_row, e->step_dev, e->dec_ids, e->dec_work,
+                    e->row_tail, e->last_tail, e->ones};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (e->h_stage) hipHostFree(e->h_stage);
@@ -284,20 +300,35 @@ extern "C" int dh_engine_forward(dh_engine* e, const int64_t* ids, const int32_t
         h_meta[i] = i;
         h_meta[B + i] = t;
         h_meta[2 * B + i] = h_seq_len[i];
-        h_meta[3 * B + i] = h_pos0[i];
+        h_meta[3 * B + i] = max_q == 1 ? h_pos0[i] + 1 : h_pos0[i];   // single-token call: kv_len
         for (int j = 0; j < h_seq_len[i]; ++j, ++t) { h_slot[t] = i; h_pos[t] = h_pos0[i] + j; }
         h_meta[4 * B + i] = t - 1;
+    }
+    // Q11: rows torch's CPU bf16 rsqrt would process in its scalar tail loop
+    uint8_t* h_tail = reinterpret_cast<uint8_t*>(hs_ + 2 * (size_t)e->max_tokens + 5 * (size_t)B);
+    uint8_t* h_last_tail = h_tail + e->max_tokens;
+    if (e->rsqrt_vec > 0) {
+        const int V = e->rsqrt_vec;
+        int r = 0;
+        for (int i = 0; i < n_seq; ++i) {
+            for (int j = 0; j < h_seq_len[i]; ++j, ++r)
+                h_tail[r] = e->rsqrt_whole ? (r >= n_tok / V * V) : (j >= h_seq_len[i] / V * V);
+            h_last_tail[i] = h_tail[r - 1];   // ln_f runs on all rows in the reference: the last row keeps its flag
+        }
+        DH_HIP(hipMemcpyAsync(e->row_tail, h_tail, n_tok, hipMemcpyHostToDevice, s));
+        DH_HIP(hipMemcpyAsync(e->last_tail, h_last_tail, n_seq, hipMemcpyHostToDevice, s));
     }
     DH_HIP(hipMemcpyAsync(e->tok_slot, h_slot, n_tok * sizeof(int32_t), hipMemcpyHostToDevice, s));
     DH_HIP(hipMemcpyAsync(e->tok_pos, h_pos, n_tok * sizeof(int32_t), hipMemcpyHostToDevice, s));
     DH_HIP(hipMemcpyAsync(e->seq_meta, h_meta, 4 * B * sizeof(int32_t), hipMemcpyHostToDevice, s));
     DH_HIP(hipMemcpyAsync(e->last_row, h_meta + 4 * B, B * sizeof(int32_t), hipMemcpyHostToDevice, s));
     int rc;
-    if ((rc = run_layers(e, ids, n_tok, n_seq, max_q, false, s))) return rc;
+    // one token per sequence == a decode step (what generate()'s loop issues): same kernels as dh_engine_decode
+    if ((rc = run_layers(e, ids, n_tok, n_seq, max_q, max_q == 1, e->row_tail, s))) return rc;
     e->last_ntok = n_tok;
     if (logits_all) {
         // ln_f output lands in e->xn (test hook dh_engine_hidden)
-        if ((rc = head(e, e->x, n_tok, logits_all, s))) return rc;
+        if ((rc = head(e, e->x, n_tok, logits_all, e->row_tail, s))) return rc;
     }
     if (logits_last) {
         hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(n_seq, 4)), dim3(256), 0, s, e->x, e->last_row, e->xlast, n_seq,
@@ -307,7 +338,7 @@ extern "C" int dh_engine_forward(dh_engine* e, const int64_t* ids, const int32_t
             // xn currently holds ln_f(x) of all rows; recompute for the gathered rows into a scratch
             // region past them is unnecessary: head() overwrites xn[0:n_seq], which is fine after logits_all.
         }
-        if ((rc = head(e, e->xlast, n_seq, logits_last, s))) return rc;
+        if ((rc = head(e, e->xlast, n_seq, logits_last, e->last_tail, s))) return rc;
     }
     return 0;
 }
@@ -321,8 +352,8 @@ int decode_step(dh_engine* e, int64_t* tokens, int tok_ld, int32_t* length, int3
                        e->tok_slot, e->tok_pos, kv_len, e->step_dev, n_seq, e->s_max);
     DH_LAUNCH_CHECK();
     int rc;
-    if ((rc = run_layers(e, e->dec_ids, n_seq, n_seq, 1, true, s))) return rc;
-    if ((rc = head(e, e->x, n_seq, e->logits, s))) return rc;
+    if ((rc = run_layers(e, e->dec_ids, n_seq, n_seq, 1, true, e->ones, s))) return rc;
+    if ((rc = head(e, e->x, n_seq, e->logits, e->ones, s))) return rc;
     // the per-step RNG counter lives in step_dev (incremented by decode_prep_kernel)
     return dh_sample_impl(e->logits, e->d.vocab, tokens, tok_ld, length, done, n_seq, temperature, top_k, eos_id,
                           seed, 0, e->step_dev, s);
@@ -348,13 +379,6 @@ extern "C" int dh_engine_decode(dh_engine* e, int64_t* tokens, int tok_ld, int32
         h_meta[e->max_batch] = fs;
         DH_HIP(hipMemcpyAsync(e->step_dev, h_meta + e->max_batch, sizeof(int32_t), hipMemcpyHostToDevice, s));
     }
-    if (e->tm.on) {  // timed runs stay eager so each kernel class can be bracketed by events
-        for (int i = 0; i < n_steps; ++i) {
-            int rc = decode_step(e, tokens, tok_ld, length, done, n_seq, temperature, top_k, eos_id, seed, s);
-            if (rc) return rc;
-        }
-        return 0;
-    }
     const bool same = e->gexec && e->gkey.tokens == tokens && e->gkey.tok_ld == tok_ld && e->gkey.length == length &&
                       e->gkey.done == done && e->gkey.n_seq == n_seq && e->gkey.top_k == top_k &&
                       e->gkey.temp == temperature && e->gkey.eos == eos_id && e->gkey.seed == seed;
@@ -365,7 +389,9 @@ extern "C" int dh_engine_decode(dh_engine* e, int64_t* tokens, int tok_ld, int32
         if (e->gexec) { hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
         hipGraph_t graph = nullptr;
         DH_HIP(hipStreamBeginCapture(e->gstream, hipStreamCaptureModeThreadLocal));
+        e->capturing = true;
         int rc = decode_step(e, tokens, tok_ld, length, done, n_seq, temperature, top_k, eos_id, seed, e->gstream);
+        e->capturing = false;
         hipError_t ce = hipStreamEndCapture(e->gstream, &graph);
         if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
         DH_CHECK(ce == hipSuccess && graph, "dh_engine_decode: graph capture failed: %s", hipGetErrorString(ce));
@@ -377,6 +403,13 @@ extern "C" int dh_engine_decode(dh_engine* e, int64_t* tokens, int tok_ld, int32
     for (int i = 0; i < n_steps; ++i) DH_HIP(hipGraphLaunch(e->gexec, e->gstream));
     DH_HIP(hipEventRecord(e->ev_out, e->gstream));
     DH_HIP(hipStreamWaitEvent(s, e->ev_out, 0));
+    return 0;
+}
+
+extern "C" int dh_engine_set_cpu_rsqrt_emulation(dh_engine* e, int vec_width, int whole_call) {
+    DH_CHECK(e && vec_width >= 0, "dh_engine_set_cpu_rsqrt_emulation: bad argument");
+    e->rsqrt_vec = vec_width;
+    e->rsqrt_whole = whole_call != 0;
     return 0;
 }
 

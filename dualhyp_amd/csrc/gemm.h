@@ -1,0 +1,32 @@
+// Argument block shared by the tiled (gemm.hip) and weight-streaming (gemm_skinny.hip) kernels.
+#pragma once
+#include "common.h"
+
+struct GemmArgs {
+    const bf16_t* x;
+    const bf16_t* w;
+    const bf16_t* w2;
+    bf16_t* y;
+    const bf16_t* xa;
+    const bf16_t* lora_b;
+    const bf16_t* vec_a;
+    const bf16_t* vec_b;
+    const bf16_t* resid;
+    int M, N, K;
+    int xa_ld, split0, split1;
+    float lora_scale;
+    int nb_n, nb_m;
+};
+
+
+// M <= 32: one pass over W straight from HBM to registers (gemm_skinny.hip)
+int dh_linear_skinny(const GemmArgs& a, int epilogue, hipStream_t s);
+
+// dh_linear_bf16 with an explicit kernel choice.  kernel: 0 = by shape (M <= 32 -> skinny),
+// 1 = tiled MFMA kernel whatever M.  The engine pins the choice per PHASE (prefill = tiled,
+// single-token decode = skinny) so a sequence's result never depends on how many other
+// sequences were packed into the same call (fp32 summation order differs between the two).
+int dh_linear_impl(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N, int K, int epilogue,
+                   const dh_bf16* w2, const dh_bf16* xa, int xa_ld, const dh_bf16* lora_b, float lora_scale,
+                   int split0, int split1, const dh_bf16* vec_a, const dh_bf16* vec_b, const dh_bf16* resid,
+                   int kernel, hipStream_t s);

@@ -17,24 +17,9 @@
 // beforehand ([M,16*segments]); each 32x32 output tile then needs ONE extra MFMA
 // lacc = lora_B[32 n,16] · xa[32 m,16]^T, and y = bf16(bf16(acc) + bf16(bf16(lacc)*s)).
 #include "common.h"
+#include "gemm.h"
 
 namespace {
-
-struct GemmArgs {
-    const bf16_t* x;
-    const bf16_t* w;
-    const bf16_t* w2;
-    bf16_t* y;
-    const bf16_t* xa;
-    const bf16_t* lora_b;
-    const bf16_t* vec_a;
-    const bf16_t* vec_b;
-    const bf16_t* resid;
-    int M, N, K;
-    int xa_ld, split0, split1;
-    float lora_scale;
-    int nb_n, nb_m;
-};
 
 constexpr int BT = 128;   // block tile edge (both n and m)
 constexpr int BK = 64;
@@ -232,6 +217,14 @@ extern "C" int dh_linear_bf16(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, in
                               const dh_bf16* w2, const dh_bf16* xa, int xa_ld, const dh_bf16* lora_b,
                               float lora_scale, int split0, int split1, const dh_bf16* vec_a,
                               const dh_bf16* vec_b, const dh_bf16* resid, void* stream) {
+    return dh_linear_impl(x, w, y, M, N, K, epilogue, w2, xa, xa_ld, lora_b, lora_scale, split0, split1, vec_a, vec_b,
+                          resid, 0, (hipStream_t)stream);
+}
+
+int dh_linear_impl(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N, int K, int epilogue,
+                   const dh_bf16* w2, const dh_bf16* xa, int xa_ld, const dh_bf16* lora_b, float lora_scale,
+                   int split0, int split1, const dh_bf16* vec_a, const dh_bf16* vec_b, const dh_bf16* resid,
+                   int kernel, hipStream_t s) {
     DH_CHECK(M >= 0 && N > 0 && K > 0, "dh_linear_bf16: bad shape M=%d N=%d K=%d", M, N, K);
     DH_CHECK(K % BK == 0, "dh_linear_bf16: K=%d must be a multiple of %d", K, BK);
     DH_CHECK(N % 8 == 0, "dh_linear_bf16: N=%d must be a multiple of 8", N);
@@ -243,23 +236,23 @@ extern "C" int dh_linear_bf16(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, in
     a.lora_scale = lora_scale;
     a.nb_m = cdiv(M, BT);
     a.nb_n = (epilogue == DH_EPI_SWIGLU) ? cdiv(N, 64) : cdiv(N, BT);
-    hipStream_t s = (hipStream_t)stream;
+    const bool skinny = kernel == 0 && M <= 32 && K % 32 == 0;   // weight-streaming kernel (gemm_skinny.hip)
     switch (epilogue) {
         case DH_EPI_PLAIN:
-            return launch<DH_EPI_PLAIN>(a, s);
+            return skinny ? dh_linear_skinny(a, epilogue, s) : launch<DH_EPI_PLAIN>(a, s);
         case DH_EPI_LORA:
             DH_CHECK(xa && lora_b && xa_ld >= 16 && xa_ld % 8 == 0, "dh_linear_bf16: LORA epilogue needs xa/lora_b");
             DH_CHECK(split0 % 32 == 0 && split1 % 32 == 0 && split0 <= split1, "dh_linear_bf16: LoRA splits must be multiples of 32");
             DH_CHECK(xa_ld >= 16 * (1 + (split0 < N) + (split1 < N)), "dh_linear_bf16: xa_ld too small for the segments");
-            return launch<DH_EPI_LORA>(a, s);
+            return skinny ? dh_linear_skinny(a, epilogue, s) : launch<DH_EPI_LORA>(a, s);
         case DH_EPI_SWIGLU:
             DH_CHECK(w2 != nullptr, "dh_linear_bf16: SWIGLU epilogue needs w2");
             DH_CHECK(resid == nullptr, "dh_linear_bf16: SWIGLU epilogue takes no residual");
             DH_CHECK(N % 32 == 0, "dh_linear_bf16: SWIGLU needs N %% 32 == 0");
-            return launch<DH_EPI_SWIGLU>(a, s);
+            return skinny ? dh_linear_skinny(a, epilogue, s) : launch<DH_EPI_SWIGLU>(a, s);
         case DH_EPI_ADAPTER:
             DH_CHECK(vec_a && vec_b, "dh_linear_bf16: ADAPTER epilogue needs scale/bias vectors");
-            return launch<DH_EPI_ADAPTER>(a, s);
+            return skinny ? dh_linear_skinny(a, epilogue, s) : launch<DH_EPI_ADAPTER>(a, s);
         default:
             DH_CHECK(false, "dh_linear_bf16: unknown epilogue %d", epilogue);
     }

@@ -38,6 +38,7 @@ def generate_batch(model: GPT, prompts: Sequence[torch.Tensor], max_new_tokens: 
     length = torch.tensor(lens, dtype=torch.int32, device=dev)
     done = torch.zeros(B, dtype=torch.int32, device=dev)
     packed = torch.cat([p.to(dev).reshape(-1) for p in prompts])
+    eng.set_rsqrt_emulation(model.cpu_rsqrt_vec_width, whole_call=False)   # B independent batch-1 runs
     _, last = eng.forward(packed, lens, [0] * B, want_all=False, want_last=True)
     ops.sample(last, tokens, length, done, temperature=temperature, top_k=top_k, eos_id=eos_id, seed=seed, step=0)
     if max_new_tokens > 1:

@@ -362,6 +362,18 @@ class _Engine:
                 -1 if eos_id is None else int(eos_id), int(seed) & ((1 << 64) - 1), int(first_step),
                 torch.cuda.current_stream().cuda_stream))
 
+    def set_rsqrt_emulation(self, vec_width: int, whole_call: bool) -> None:
+        _lib.check(self.lib.dh_engine_set_cpu_rsqrt_emulation(self.handle, int(vec_width), int(whole_call)))
+
+    def set_timing(self, on: bool) -> None:
+        _lib.check(self.lib.dh_engine_set_timing(self.handle, int(on)))
+
+    def get_timing(self, which: int) -> Tuple[float, int]:
+        """(milliseconds, launches) of kernel class `which` since set_timing(True); see dh_engine_get_timing."""
+        ms, n = C.c_double(), C.c_int64()
+        _lib.check(self.lib.dh_engine_get_timing(self.handle, which, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def read(self, what: int, layer: int, shape) -> torch.Tensor:
         """Copy of engine state (dh_engine_read): 0 ln_f(x), 1 K cache, 2 V^T cache, 3 residual x."""
         out = torch.empty(shape, dtype=torch.bfloat16, device=self.device)
@@ -390,6 +402,10 @@ class GPT(nn.Module):
         self.max_seq_length = config.block_size
         self.mask_cache: Optional[torch.Tensor] = None   # never built: causality is implicit in the kernels
         self.kv_caches: List[KVCache] = []                # kept for API parity; the engine owns the cache
+        # Lanes of torch's bf16 vector loop on the host whose CPU run of the reference is to be
+        # reproduced bit for bit (32 = AVX-512, 16 = AVX2); 0 = round rsqrt once, like a GPU run of
+        # the reference.  See dh_rmsnorm_bf16 / DESIGN.md Q11.
+        self.cpu_rsqrt_vec_width = 32
         self._engine: Optional[_Engine] = None
         self._capacity = dict(max_batch=1, s_max=0, max_tokens=0)
         self._cache_len: List[int] = []                   # tokens currently valid per cache slot
@@ -495,6 +511,7 @@ class GPT(nn.Module):
         if use_kv_cache:
             if p0 > 0 and (len(self._cache_len) < B or any(c != p0 for c in self._cache_len[:B])):
                 raise RuntimeError(f"KV cache holds {self._cache_len[:B]} tokens but input_pos starts at {p0}")
+        eng.set_rsqrt_emulation(self.cpu_rsqrt_vec_width, whole_call=True)
         la, _ = eng.forward(idx, [T] * B, [p0] * B, want_all=True, want_last=False)
         self._cache_len = [p0 + T] * B if use_kv_cache else []
         logits = la.view(B, T, -1)

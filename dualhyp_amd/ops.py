@@ -41,7 +41,7 @@ def embed(ids: torch.Tensor, wte: torch.Tensor) -> torch.Tensor:
 
 
 def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, resid: Optional[torch.Tensor] = None,
-            return_sum: bool = False):
+            return_sum: bool = False, row_tail: Optional[torch.Tensor] = None):
     x = _dev(x, name="x")
     w = _dev(w, name="weight")
     d = x.size(-1)
@@ -50,7 +50,11 @@ def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, resid: Optional[torch.
     s = torch.empty_like(x) if (resid is not None and return_sum) else None
     if resid is not None:
         resid = _dev(resid, name="resid")
-    check(_lib.load().dh_rmsnorm_bf16(_p(x), _p(resid), _p(w), _p(out), _p(s), rows, d, float(eps), _stream()))
+    if row_tail is not None:
+        row_tail = _dev(row_tail.reshape(-1), torch.uint8, "row_tail")
+        assert row_tail.numel() == rows
+    check(_lib.load().dh_rmsnorm_bf16(_p(x), _p(resid), _p(w), _p(out), _p(s), rows, d, float(eps), _p(row_tail),
+                                      _stream()))
     return (out, s) if return_sum else out
 
 

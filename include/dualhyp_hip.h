@@ -42,9 +42,14 @@ int dh_embed_bf16(const int64_t* ids, const dh_bf16* wte, dh_bf16* out, int n_to
 /* RMSNorm in the storage dtype — ger/rmsnorm.py:17-21:
  *   ms = bf16(mean_fp32(bf16(x*x))) ; r = bf16(rsqrt(bf16(ms+eps))) ; out = bf16(w*bf16(x*r))
  * If `resid` is non-NULL the input is x := bf16(x + resid) and `sum_out` (if non-NULL)
- * receives that sum (the residual stream update of ger/model.py:185-186). */
+ * receives that sum (the residual stream update of ger/model.py:185-186).
+ * row_tail (nullable, uint8 per row): rows flagged non-zero use r = bf16(1 / bf16(sqrt(t)))
+ * instead of bf16(1/sqrt(t)).  That is what the reference's CPU path computes for the rows
+ * torch's bf16 rsqrt handles in its scalar tail loop (the last n %% 32 rows of a call on AVX-512
+ * hosts, hence every single-token decode call) — SURVEY.md quirk list, DESIGN.md Q11. */
 int dh_rmsnorm_bf16(const dh_bf16* x, const dh_bf16* resid, const dh_bf16* w, dh_bf16* out,
-                    dh_bf16* sum_out, int rows, int d, float eps, void* stream);
+                    dh_bf16* sum_out, int rows, int d, float eps, const uint8_t* row_tail,
+                    void* stream);
 
 /* Split the fused QKV projection, rotate q and k, append k/v to the KV cache —
  * ger/model.py:216-259.  qkv: [n_tok, n_groups*(q_per_kv+2)*hs] in the group-interleaved layout
@@ -171,6 +176,14 @@ int64_t dh_engine_device_bytes(const dh_engine* e);
 int dh_engine_forward(dh_engine* e, const int64_t* ids, const int32_t* h_seq_len,
                       const int32_t* h_pos0, int n_seq, dh_bf16* logits_all,
                       dh_bf16* logits_last, void* stream);
+
+/* Reproduce the rsqrt rounding of the reference's CPU path (see dh_rmsnorm_bf16 row_tail):
+ * vec_width = lanes of torch's bf16 vector loop on the reference host (32 on AVX-512, 16 on
+ * AVX2), 0 = off (every row uses bf16(1/sqrt(t)), as a GPU run of the reference would).
+ * whole_call = 1: the tail is the last n_tok %% vec_width rows of the packed call (what
+ * GPT.forward(idx[B,T]) does); 0: per sequence (B independent batch-1 calls, generate()).
+ * Decode steps are single-token calls, i.e. always tail rows.  Default: off. */
+int dh_engine_set_cpu_rsqrt_emulation(dh_engine* e, int vec_width, int whole_call);
 
 /* The decode loop of generate/base.py:57-80 for n_seq sequences at once, entirely on device:
  * tokens [n_seq, tok_ld] holds the prompts (length[i] valid ids each, already prefilled

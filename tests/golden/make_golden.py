@@ -298,6 +298,20 @@ def gen_full(rlora, rgenerate, name: str, seed: int, T: int, G: int) -> None:
         m.reset_cache()
     out["generate_margins_ulps"] = torch.tensor(margins)
     out["step_logits"] = torch.stack(step_logits)
+    # fp32 run of the same weights, teacher-forced on the bf16 ids: the yardstick for "how far is
+    # a bf16 implementation from the real-valued function" (first 4096 vocab entries only)
+    del m
+    sd = synth_state_dict(cfg, seed=seed)
+    m32 = ref_model(rlora, cfg_kwargs_of(cfg), sd, torch.float32)
+    del sd
+    f32 = []
+    with torch.no_grad():
+        lg = m32(idx.view(1, -1), torch.arange(T))[0, -1]
+        for s in range(G):
+            f32.append(lg[:4096].clone())
+            if s + 1 < G:
+                lg = m32(g[T + s].view(1, 1), torch.tensor([T + s]))[0, 0]
+    out["step_logits_fp32_v4096"] = torch.stack(f32)
     save(name, out, {"config": cfg_kwargs_of(cfg), "seed": seed, "T": T, "G": G})
 
 

@@ -23,8 +23,10 @@ def U(shape, bound, name, seed=11):
     return uniform(shape, bound, stream_id(seed, name))
 
 
-def check_ulp(got, want, max_ulp, max_frac, what):
-    u = ulp_diff(got.float().cpu(), want.float())
+def check_ulp(got, want, max_ulp, max_frac, what, floor_frac=1.0):
+    """floor_frac = 1: yardstick is the bf16 ulp at max(|a|,|b|,rms) — right for results that are
+    sums of O(rms) rounded intermediates (residual adds, LoRA adds, attention averages)."""
+    u = ulp_diff(got.float().cpu(), want.float(), floor_frac)
     frac = (u > 0).float().mean().item()
     assert u.max().item() <= max_ulp and frac <= max_frac, f"{what}: max {u.max().item():.2f} ulp, {frac:.3%} of elements differ"
     return u.max().item(), frac
@@ -36,12 +38,23 @@ def test_rmsnorm(dev, rows, d):
     from oracle import ger_oracle as O
     x = U((rows, d), 2.0, f"x{d}")
     w = (1 + U((d,), 0.25, f"w{d}").float()).bfloat16()
-    got = ops.rmsnorm(x.to(dev), w.to(dev), 1e-5)
-    check_ulp(got, O.rmsnorm(x, w, 1e-5), 1, 0.02, "rmsnorm")
+    # torch's CPU bf16 rsqrt rounds differently in its vector loop and its scalar tail (the last
+    # rows % 32 of the call); row_tail reproduces that, so the match is bit-exact
+    # up to fp32 summation order in the mean.
+    tail = (torch.arange(rows) >= rows // 32 * 32).to(torch.uint8)
+    got = ops.rmsnorm(x.to(dev), w.to(dev), 1e-5, row_tail=tail.to(dev))
+    check_ulp(got, O.rmsnorm(x, w, 1e-5), 1, 0.002, "rmsnorm")
     r = U((rows, d), 1.0, f"r{d}")
-    got, s = ops.rmsnorm(x.to(dev), w.to(dev), 1e-5, resid=r.to(dev), return_sum=True)
+    got, s = ops.rmsnorm(x.to(dev), w.to(dev), 1e-5, resid=r.to(dev), return_sum=True, row_tail=tail.to(dev))
     assert torch.equal(s.cpu(), x + r)
-    check_ulp(got, O.rmsnorm(x + r, w, 1e-5), 1, 0.02, "add+rmsnorm")
+    check_ulp(got, O.rmsnorm(x + r, w, 1e-5), 1, 0.002, "add+rmsnorm")
+    # without flags every row uses the single-rounding form
+    xf = x.float()
+    rb = lambda v: v.bfloat16().float()
+    rr = rb(1 / torch.sqrt(rb(rb(rb(xf * xf).sum(-1, keepdim=True) / d) + 1e-5)))
+    want = rb(w.float() * rb(xf * rr))
+    got = ops.rmsnorm(x.to(dev), w.to(dev), 1e-5)
+    assert (got.float().cpu() != want).float().mean().item() < 0.002
 
 
 def test_embed(dev):
@@ -56,9 +69,9 @@ def test_linear_plain_and_resid(dev, M, N, K):
     from dualhyp_amd import ops
     x, w = U((M, K), 1.0, "lx"), U((N, K), 0.05, "lw")
     want = torch.nn.functional.linear(x, w)
-    check_ulp(ops.linear(x.to(dev), w.to(dev)), want, 1, 0.02, "linear")
+    check_ulp(ops.linear(x.to(dev), w.to(dev)), want, 1, 0.002, "linear", floor_frac=1 / 16)
     r = U((M, N), 1.0, "lr")
-    check_ulp(ops.linear(x.to(dev), w.to(dev), resid=r.to(dev)), r + want, 1, 0.02, "linear+resid")
+    check_ulp(ops.linear(x.to(dev), w.to(dev), resid=r.to(dev)), r + want, 2, 0.002, "linear+resid")
 
 
 @pytest.mark.parametrize("M,d,r", [(70, 256, 4), (130, 2048, 16)])
@@ -82,7 +95,7 @@ def test_linear_lora(dev, M, d, r):
     xd = x.to(dev)
     xa = ops.linear(xd, A48.to(dev))
     got = ops.linear(xd, W.to(dev), epilogue=ops.EPI_LORA, xa=xa, lora_b=B16.to(dev), lora_scale=s, splits=(d, d + kv))
-    check_ulp(got, want, 1, 0.02, "qkv lora")
+    check_ulp(got, want, 2, 0.002, "qkv lora")
     # single-segment (attn.proj) with fused residual
     Wp, Ap, Bp = U((d, d), 0.05, "pw"), U((r, d), 1 / math.sqrt(d), "pa"), U((d, r), 0.05, "pb")
     res = U((1, M, d), 1.0, "pr")
@@ -90,7 +103,7 @@ def test_linear_lora(dev, M, d, r):
     xa = ops.linear(xd, _pad_rank(Ap, r, 0).to(dev))
     got = ops.linear(xd, Wp.to(dev), epilogue=ops.EPI_LORA, xa=xa, lora_b=_pad_rank(Bp, r, 1).to(dev), lora_scale=s,
                      resid=res.to(dev))
-    check_ulp(got, want, 1, 0.02, "proj lora + resid")
+    check_ulp(got, want, 2, 0.002, "proj lora + resid")
 
 
 @pytest.mark.parametrize("M,d,I", [(50, 256, 384), (200, 2048, 5632)])
@@ -99,12 +112,45 @@ def test_linear_swiglu_and_adapter(dev, M, d, I):
     x, w1, w2 = U((M, d), 1.0, "sx"), U((I, d), 0.05, "s1"), U((I, d), 0.05, "s2")
     F = torch.nn.functional
     want = F.silu(F.linear(x, w1)) * F.linear(x, w2)
-    check_ulp(ops.linear(x.to(dev), w1.to(dev), epilogue=ops.EPI_SWIGLU, w2=w2.to(dev)), want, 1, 0.03, "swiglu")
+    check_ulp(ops.linear(x.to(dev), w1.to(dev), epilogue=ops.EPI_SWIGLU, w2=w2.to(dev)), want, 2, 0.003, "swiglu")
     sc = (1 + U((I,), 0.5, "sc").float()).bfloat16()
     bi = U((I,), 0.5, "bi")
     want = sc * (F.linear(x, w1) + bi)
     check_ulp(ops.linear(x.to(dev), w1.to(dev), epilogue=ops.EPI_ADAPTER, scale=sc.to(dev), bias=bi.to(dev)), want,
-              1, 0.02, "adapter")
+              2, 0.002, "adapter")
+
+
+@pytest.mark.parametrize("M", [1, 7, 32])
+@pytest.mark.parametrize("d,I,r", [(256, 384, 4), (2048, 5632, 16)])
+def test_linear_decode_shapes(dev, M, d, I, r):
+    """M <= 32 takes the weight-streaming kernel (gemm_skinny.hip): all four epilogues."""
+    from dualhyp_amd import ops
+    from dualhyp_amd.gpt import _pad_rank
+    from oracle import ger_oracle as O
+    F = torch.nn.functional
+    x = U((1, M, d), 1.0, f"dx{M}")
+    kv = d // 2
+    N = d + 2 * kv
+    W, A, B = U((N, d), 0.05, "dw"), U((3 * r, d), 1 / math.sqrt(d), "da"), U((N, r), 0.05, "db")
+    A48 = torch.zeros(48, d, dtype=torch.bfloat16)
+    for seg in range(3):
+        A48[16 * seg:16 * seg + r] = A[seg * r:(seg + 1) * r]
+    xd = x.to(dev)
+    xa = ops.linear(xd, A48.to(dev))
+    check_ulp(xa[..., :r], F.linear(x, A)[..., :r], 1, 0.01, "xa", floor_frac=1 / 16)
+    got = ops.linear(xd, W.to(dev), epilogue=ops.EPI_LORA, xa=xa, lora_b=_pad_rank(B, r, 1).to(dev), lora_scale=2.0,
+                     splits=(d, d + kv))
+    check_ulp(got, O.lora_qkv_linear(x, W, A, B, 2.0, (d, kv, kv)), 2, 0.01, "decode qkv lora")
+    w1, w2, wp = U((I, d), 0.05, "d1"), U((I, d), 0.05, "d2"), U((d, I), 0.05, "dp")
+    act_ref = F.silu(F.linear(x, w1)) * F.linear(x, w2)
+    act = ops.linear(xd, w1.to(dev), epilogue=ops.EPI_SWIGLU, w2=w2.to(dev))
+    check_ulp(act, act_ref, 2, 0.01, "decode swiglu")
+    res = U((1, M, d), 1.0, "dres")
+    got = ops.linear(act_ref.to(dev), wp.to(dev), resid=res.to(dev))
+    check_ulp(got, res + F.linear(act_ref, wp), 2, 0.01, "decode mlp proj + resid")
+    sc, bi = (1 + U((N,), 0.5, "dsc").float()).bfloat16(), U((N,), 0.5, "dbi")
+    got = ops.linear(xd, W.to(dev), epilogue=ops.EPI_ADAPTER, scale=sc.to(dev), bias=bi.to(dev))
+    check_ulp(got, sc * (F.linear(x, W) + bi), 2, 0.01, "decode adapter")
 
 
 def _attn_setup(dev, hs, n_head, n_groups, lens, pos0, s_max, seed):
@@ -167,9 +213,12 @@ def test_qkv_rope_cache_and_prefill_attention(dev, hs, n_head, n_groups):
         err_hip = (got - truth).abs().max().item()
         err_ref = (want.float() - truth).abs().max().item()
         assert err_hip <= max(2 * err_ref, 2e-2), f"prefill attention: hip err {err_hip} vs reference-kernel err {err_ref}"
-        u = ulp_diff(got, want.float())
+        u = ulp_diff(got, want.float(), 1.0)
         worst = max(worst, u.max().item())
-        assert u.max().item() <= 4 and (u > 1).float().mean().item() < 0.01, f"{u.max().item()} ulp"
+        # the reference's CPU kernel takes one KV block (<= 512 keys) against the final row max; this kernel
+        # walks 64-key tiles with a running max, so P is rounded to bf16 at a different scale on
+        # rows whose max moves: 1-ulp differences on up to ~15% of outputs at T = 128
+        assert u.max().item() <= 2.5 and (u > 0).float().mean().item() < 0.20, f"{u.max().item()} ulp, {(u > 0).float().mean().item():.2%} differ"
         t0 += n
 
 
