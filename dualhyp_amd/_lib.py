@@ -33,12 +33,16 @@ class ModelDesc(C.Structure):
 # name -> (restype, argtypes); must list every function declared in include/dualhyp_hip.h
 SIGNATURES = {
     "dh_abi_version": (I, []),
+    "dh_set_tuning": (I, [I, I]),
     "dh_last_error": (C.c_char_p, []),
     "dh_device_info": (I, [C.c_char_p, I, C.POINTER(I), C.POINTER(I64)]),
     "dh_embed_bf16": (I, [P, P, P, I, I, I, P]),
     "dh_rmsnorm_bf16": (I, [P, P, P, P, P, I, I, F, P, P]),
     "dh_qkv_rope_cache_bf16": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "dh_linear_bf16": (I, [P, P, P, I, I, I, I, P, P, I, P, F, I, I, P, P, P, P]),
+    "dh_linear_partial_bf16": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "dh_finish_norm_bf16": (I, [P, I, I, I, I, P, F, P, P, P, P, F, P, P]),
+    "dh_attn_decode_fused_bf16": (I, [P, I, I, I, I, P, F, I, I, P, P, P, P, P, P, P, I, I, I, I, P]),
     "dh_attn_prefill_bf16": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "dh_attn_decode_work_bytes": (I64, [I, I, I, I]),
     "dh_attn_decode_bf16": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),

@@ -1,8 +1,13 @@
 // Causal GQA attention against the compact KV cache (ger/model.py:261,270-290).
 //
-// Layout chosen for the MFMA operand maps, not inherited from the reference:
-//   K   cache [slot, group, s_max, hs]   (row = key, hs contiguous)
-//   V^T cache [slot, group, hs, s_max]   (row = channel, keys contiguous)
+// Layout chosen for the MFMA operand maps, not inherited from the reference: both caches are stored
+// in MFMA-FRAGMENT ORDER (common.h kfrag_off / vfrag_off): per (slot, group) a sequence of 32-key
+// tiles, each tile a run of 1-KiB blocks that are, byte for byte, the A-operand fragments of
+//   S^T = K . Q^T   (block (ks): lane i holds K[key i&31][16ks + 8(i>>5) .. +8])
+//   O^T = V^T . P^T (block (dt,s2): lane i holds V[8 permuted keys][d = 32dt + (i&31)])
+// so a decode wave streams a tile as 8 fully coalesced 1-KiB loads straight into MFMA operands,
+// and the prefill kernel copies tiles linearly into LDS and reads them back lane-linear
+// (conflict-free ds_read_b128, no swizzle).
 // Both products keep the QUERY on the accumulator's lane axis:
 //   S^T[key][q] = K · Q^T      A = K rows (16 B of a key row),  B = Q rows (16 B of a q row)
 //   O^T[d][q]   = V^T · P^T    A = V^T rows (keys contiguous),  B = the S^T accumulator itself,
@@ -18,9 +23,6 @@
 
 namespace {
 
-template <int HS> __device__ __forceinline__ int swzK(int key) { return HS == 64 ? ((key >> 1) & 7) : (key & 15); }
-__device__ __forceinline__ int swzV(int d) { return (d >> 1) & 15; }
-
 // ------------------------------------------------------------------------------------ prefill
 // grid (q tiles of 32, n_groups, n_seq); block = 64 * q_per_kv threads: one wave per query head
 // of the group, all waves share the K / V^T tiles of 64 keys staged in LDS.
@@ -31,9 +33,9 @@ __global__ __launch_bounds__(HS == 64 ? 1024 : 512) void attn_prefill_kernel(
     const int32_t* __restrict__ kv_pos0, bf16_t* __restrict__ y, int n_head, int n_groups, int s_max, float scale) {
     constexpr int KS = HS / 16;   // k-steps of the QK product
     constexpr int DT = HS / 32;   // 32-row tiles of O^T
-    constexpr int KCH = HS / 8;   // 16-B chunks per K row
-    __shared__ __attribute__((aligned(16))) char sK[64 * HS * 2];
-    __shared__ __attribute__((aligned(16))) char sV[HS * 64 * 2];
+    constexpr int TILE_B = HS * 32 * 2;   // bytes of one 32-key tile of K (and of V^T)
+    __shared__ __attribute__((aligned(16))) char sK[2 * TILE_B];
+    __shared__ __attribute__((aligned(16))) char sV[2 * TILE_B];
 
     const int seq = blockIdx.z, g = blockIdx.y;
     const int qt = gridDim.x - 1 - blockIdx.x;          // longest (latest) tiles first
@@ -73,26 +75,15 @@ __global__ __launch_bounds__(HS == 64 ? 1024 : 512) void attn_prefill_kernel(
     for (int kt = 0; kt < n_tiles; ++kt) {
         const int key0 = kt * 64;
         __syncthreads();
-        // ---- stage K tile [64 keys][HS] and V^T tile [HS][64 keys]; zero beyond last_key
-        for (int c = tid; c < 64 * KCH; c += nthr) {
-            const int key = c / KCH, ch = c % KCH;
-            uint4 u = make_uint4(0, 0, 0, 0);
-            if (key0 + key <= last_key) u = *reinterpret_cast<const uint4*>(kbase + (size_t)(key0 + key) * HS + ch * 8);
-            *reinterpret_cast<uint4*>(sK + key * (HS * 2) + ((ch ^ swzK<HS>(key)) << 4)) = u;
-        }
-        for (int c = tid; c < HS * 8; c += nthr) {
-            const int d = c >> 3, kc = c & 7;            // kc: 16-B chunk = 8 keys
-            uint4 u = *reinterpret_cast<const uint4*>(vbase + (size_t)d * s_max + key0 + kc * 8);
-            const int k8 = key0 + kc * 8;
-            if (k8 + 7 > last_key) {                     // partial / empty chunk: zero the tail
-                bf16_t* e = reinterpret_cast<bf16_t*>(&u);
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (k8 + j > last_key) e[j] = 0;
+        // ---- stage the two 32-key tiles of K and of V^T: linear copies (the cache is already in
+        // fragment order).  Keys beyond last_key are masked below; the cache is finite everywhere.
+        {
+            const uint4* gk = reinterpret_cast<const uint4*>(kbase + (size_t)(2 * kt) * HS * 32);
+            const uint4* gv = reinterpret_cast<const uint4*>(vbase + (size_t)(2 * kt) * HS * 32);
+            for (int c = tid; c < 2 * TILE_B / 16; c += nthr) {
+                reinterpret_cast<uint4*>(sK)[c] = gk[c];
+                reinterpret_cast<uint4*>(sV)[c] = gv[c];
             }
-            const int sv = swzV(d);
-            *reinterpret_cast<uint2*>(sV + d * 128 + (((kc * 2) ^ sv) << 3)) = make_uint2(u.x, u.y);
-            *reinterpret_cast<uint2*>(sV + d * 128 + (((kc * 2 + 1) ^ sv) << 3)) = make_uint2(u.z, u.w);
         }
         __syncthreads();
 
@@ -102,10 +93,9 @@ __global__ __launch_bounds__(HS == 64 ? 1024 : 512) void attn_prefill_kernel(
         for (int rt = 0; rt < 2; ++rt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) st[rt][r] = 0.f;
-            const int key = rt * 32 + lr;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + key * (HS * 2) + (((ks * 2 + lh) ^ swzK<HS>(key)) << 4));
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + (rt * KS + ks) * 1024 + lane * 16);
                 st[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[rt], 0, 0, 0);
             }
         }
@@ -148,15 +138,10 @@ __global__ __launch_bounds__(HS == 64 ? 1024 : 512) void attn_prefill_kernel(
                 union { bf16x8 v; uint32_t u[4]; } pf;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) pf.u[j] = pack2bf(st[rt][8 * s + 2 * j], st[rt][8 * s + 2 * j + 1]);
-                const int c8 = rt * 8 + 4 * s + lh;      // 8-B chunk of keys 16s+4h.. ; +2 -> +8 keys
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    const int d = dt * 32 + lr;
-                    const int sv = swzV(d);
-                    union { bf16x8 v; uint2 h[2]; } vf;
-                    vf.h[0] = *reinterpret_cast<const uint2*>(sV + d * 128 + ((c8 ^ sv) << 3));
-                    vf.h[1] = *reinterpret_cast<const uint2*>(sV + d * 128 + (((c8 + 2) ^ sv) << 3));
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o[dt], 0, 0, 0);
+                    const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sV + (((rt * DT + dt) * 2 + s) * 1024) + lane * 16);
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, o[dt], 0, 0, 0);
                 }
             }
     }
@@ -220,24 +205,19 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(
     for (int t = wg; t < n_tiles; t += nw) {
         const int key0 = t * 32;
         // issue all loads of the tile first (K: KS x 16 B, V^T: DT x 2 x 2 x 8 B per lane)
+        // one 32-key tile = 8 coalesced 1-KiB loads that ARE the MFMA fragments (keys >= len are
+        // masked below; their cache bytes are finite)
         bf16x8 kf[KS];
-        const int key = key0 + lr;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (key < len) z = *reinterpret_cast<const bf16x8*>(kbase + (size_t)key * HS + ks * 16 + lh * 8);
-            kf[ks] = z;
-        }
-        union VF { bf16x8 v; uint2 h[2]; };
+        for (int ks = 0; ks < KS; ++ks)
+            kf[ks] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(kbase + kfrag_blk<HS>(t, ks) + lane * 8));
+        struct VF { bf16x8 v; };
         VF vf[DT][2];
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16_t* vp = vbase + (size_t)(dt * 32 + lr) * s_max + key0 + 16 * s + 4 * lh;
-                vf[dt][s].h[0] = *reinterpret_cast<const uint2*>(vp);
-                vf[dt][s].h[1] = *reinterpret_cast<const uint2*>(vp + 8);
-            }
+            for (int s = 0; s < 2; ++s)
+                vf[dt][s].v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(vbase + vfrag_blk<HS>(t, dt, s) + lane * 8));
         f32x16 st;
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[r] = 0.f;

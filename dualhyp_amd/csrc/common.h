@@ -46,6 +46,29 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// ---- KV cache in MFMA-fragment order --------------------------------------------------------
+// Both caches are stored per (slot, group) as 32-key tiles of HS*32 elements, laid out so that a
+// wave-wide contiguous 1-KiB load (lane i <- 16 B at i*16) IS an MFMA operand fragment:
+//   K  tile: [ks = d/16][lh = (d/8)&1][lr = key&31][8 d]      A operand of S^T = K.Q^T  (k-step ks)
+//   V^T tile: [dt = d/32][s2][lh][lr = d&31][8 keys]          A operand of O^T = V^T.P^T (k-step s2),
+//             the 8 keys being 16*s2 + 8*(j>>2) + 4*lh + (j&3), j = 0..7 — the k-order in which the
+//             S^T accumulator registers come out (cdna_hip_programming.md §3).
+// Offsets below are in elements from the start of the (slot, group) block of s_max*HS elements.
+template <int HS>
+__device__ __forceinline__ size_t kfrag_off(int key, int d) {
+    const int t = key >> 5, lr = key & 31, ks = d >> 4, lh = (d >> 3) & 1, e = d & 7;
+    return ((size_t)((t * (HS / 16) + ks) * 2 + lh) * 32 + lr) * 8 + e;
+}
+template <int HS>
+__device__ __forceinline__ size_t vfrag_off(int key, int d) {
+    const int t = key >> 5, kk = key & 31, s2 = kk >> 4, r = kk & 15;
+    const int j = ((r >> 3) << 2) | (r & 3), lh = (r >> 2) & 1, dt = d >> 5, lr = d & 31;
+    return ((size_t)(((t * (HS / 32) + dt) * 2 + s2) * 2 + lh) * 32 + lr) * 8 + j;
+}
+// start (in elements) of the 1-KiB fragment block of tile t: K k-step ks / V^T (dt, s2); add lane*8
+template <int HS> __device__ __forceinline__ size_t kfrag_blk(int t, int ks) { return (size_t)(t * (HS / 16) + ks) * 512; }
+template <int HS> __device__ __forceinline__ size_t vfrag_blk(int t, int dt, int s2) { return (size_t)((t * (HS / 32) + dt) * 2 + s2) * 512; }
+
 // ---- host-side error plumbing -------------------------------------------------------------
 void dh_set_error(const char* fmt, ...);
 

@@ -158,14 +158,15 @@ __global__ __launch_bounds__(256) void qkv_rope_cache_kernel(
             o1p[e] = f2bf(rbf(x1 * bf2f(c1p[e])) + rbf(-x2 * bf2f(s1p[e])));
             o2p[e] = f2bf(rbf(x2 * bf2f(c2p[e])) + rbf(x1 * bf2f(s2p[e])));
         }
-        bf16_t* dst;
         if (j < q_per_kv) {
-            dst = q_out + ((size_t)t * n_head + g * q_per_kv + j) * HS;
-        } else {
-            dst = k_cache + (((size_t)tok_slot[t] * n_groups + g) * s_max + pos) * HS;
+            bf16_t* dst = q_out + ((size_t)t * n_head + g * q_per_kv + j) * HS;
+            *reinterpret_cast<uint4*>(dst + c * 8) = o1;
+            *reinterpret_cast<uint4*>(dst + HALF + c * 8) = o2;
+        } else {   // K cache in MFMA-fragment order: 8 aligned channels stay one 16-B store
+            bf16_t* kb = k_cache + ((size_t)tok_slot[t] * n_groups + g) * s_max * HS;
+            *reinterpret_cast<uint4*>(kb + kfrag_off<HS>(pos, c * 8)) = o1;
+            *reinterpret_cast<uint4*>(kb + kfrag_off<HS>(pos, HALF + c * 8)) = o2;
         }
-        *reinterpret_cast<uint4*>(dst + c * 8) = o1;
-        *reinterpret_cast<uint4*>(dst + HALF + c * 8) = o2;
     }
 
     // phase 2: v -> V^T cache through an LDS transpose (adjacent lanes = adjacent tokens)
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256) void qkv_rope_cache_kernel(
         const int tl = it & 63, dd = it >> 6;
         const int t = t0 + tl;
         if (t < n_tok) {
-            vT_cache[(((size_t)tok_slot[t] * n_groups + g) * HS + dd) * s_max + tok_pos[t]] = vt[tl][dd];
+            vT_cache[((size_t)tok_slot[t] * n_groups + g) * HS * s_max + vfrag_off<HS>(tok_pos[t], dd)] = vt[tl][dd];
         }
     }
 }

@@ -36,6 +36,7 @@ struct dh_engine {
     int rsqrt_vec = 0, rsqrt_whole = 0;
     int64_t* dec_ids = nullptr;
     void* dec_work = nullptr;
+    float* part32 = nullptr;                            // fp32 partial sums of the decode GEMMs
     int32_t* h_stage = nullptr;                         // pinned staging for the metadata
     size_t cache_layer_elems = 0;
     int64_t dev_bytes = 0;
@@ -168,6 +169,61 @@ int run_layers(dh_engine* e, const int64_t* ids, int n_tok, int n_seq, int max_q
     return 0;
 }
 
+// K-slices of 8 (or 16 for long K) k-steps: the row-parallel streaming kernel (gemm_skinny.hip)
+int pick_ksplit(int tiles, int nks) {
+    (void)tiles;
+    if (nks <= 128) return (nks + 7) / 8;
+    if (nks <= 256) return (nks + 15) / 16;
+    int ks = 1;
+    while (ks < 4 && nks / (16 * ks) >= 2) ks *= 2;
+    return ks;
+}
+
+// Single-token step for n_seq <= 32 sequences: 7 launches per layer (decode_fused.hip).  Leaves
+// ln_f(x) in e->xn.  kv_len lives in seq_meta[3B..], seq_slot in seq_meta[0..].
+int run_layers_decode(dh_engine* e, const int64_t* ids, int n_seq, const uint8_t* tail_flags, hipStream_t s) {
+    const dh_model_desc& D = e->d;
+    const int d = D.n_embd, I = D.intermediate, hs = D.head_size, H = D.n_head, G = D.n_groups;
+    const uint8_t* rt = e->rsqrt_vec > 0 ? tail_flags : nullptr;
+    const int32_t* seq_slot = e->seq_meta;
+    const int32_t* kv_len = e->seq_meta + 3 * e->max_batch;
+    e->phase_decode = true;
+    int rc;
+    if ((rc = dh_embed_bf16(ids, D.wte, e->x, n_seq, d, D.wte_rows, s))) return rc;
+    if ((rc = dh_rmsnorm_bf16(e->x, nullptr, e->layers[0].norm_1, e->xn, nullptr, n_seq, d, D.norm_eps, rt, s))) return rc;
+    for (int l = 0; l < D.n_layer; ++l) {
+        const dh_layer_weights& W = e->layers[l];
+        bf16_t* kc = e->kc + (size_t)l * e->cache_layer_elems;
+        bf16_t* vtc = e->vtc + (size_t)l * e->cache_layer_elems;
+        const int ext1 = W.attn_lora_a ? 48 : 0;
+        const int ks1 = pick_ksplit((e->qkv_dim + ext1) / 16, d / 32);
+        if ((rc = dh_linear_partial_bf16(e->xn, W.attn_w, W.attn_lora_a, e->part32, n_seq, e->qkv_dim, ext1, d, ks1, s))) return rc;
+        if ((rc = dh_attn_decode_fused_bf16(e->part32, ks1, n_seq, e->qkv_dim, ext1, W.attn_lora_b, D.lora_scale, d,
+                                            d + e->kv_dim, D.rope_cos, D.rope_sin, seq_slot, kv_len, kc, vtc, e->att, H, G,
+                                            hs, e->s_max, s))) return rc;
+        const int ext2 = W.proj_lora_a ? 16 : 0;
+        const int ks2 = pick_ksplit((d + ext2) / 16, d / 32);
+        if ((rc = dh_linear_partial_bf16(e->att, W.proj_w, W.proj_lora_a, e->part32, n_seq, d, ext2, d, ks2, s))) return rc;
+        if ((rc = dh_finish_norm_bf16(e->part32, ks2, n_seq, d, ext2, W.proj_lora_b, D.lora_scale, e->x, W.norm_2, e->x,
+                                      e->xn, D.norm_eps, rt, s))) return rc;
+        if ((rc = linear(e, e->xn, W.fc_1, e->act, n_seq, I, d, DH_EPI_SWIGLU, W.fc_2, nullptr, 0, nullptr, 0, 0, nullptr,
+                         nullptr, nullptr, s, false))) return rc;
+        const int ks3 = pick_ksplit(d / 16, I / 32);
+        if ((rc = dh_linear_partial_bf16(e->act, W.mlp_proj, nullptr, e->part32, n_seq, d, 0, I, ks3, s))) return rc;
+        const bf16_t* next_norm = l + 1 < D.n_layer ? e->layers[l + 1].norm_1 : D.ln_f;
+        if ((rc = dh_finish_norm_bf16(e->part32, ks3, n_seq, d, 0, nullptr, 0.f, e->x, next_norm, e->x, e->xn,
+                                      D.norm_eps, rt, s))) return rc;
+    }
+    return 0;
+}
+
+// lm_head on rows that are already ln_f-normalised (e->xn)
+int head_normed(dh_engine* e, int rows, bf16_t* logits, hipStream_t s) {
+    const dh_model_desc& D = e->d;
+    return linear(e, e->xn, D.lm_head, logits, rows, D.vocab, D.n_embd, DH_EPI_ADAPTER, nullptr, nullptr, 0, nullptr, 0, 0,
+                  D.adapter_scale, D.adapter_bias, nullptr, s, true);
+}
+
 int head(dh_engine* e, const bf16_t* xrows, int rows, bf16_t* logits, const uint8_t* rt, hipStream_t s) {
     const dh_model_desc& D = e->d;
     int rc;
@@ -219,6 +275,7 @@ extern "C" int dh_engine_create(const dh_model_desc* desc, int max_batch, int s_
     rc |= dmalloc(e, &e->last_row, (size_t)max_batch);
     rc |= dmalloc(e, &e->step_dev, 1);
     rc |= dmalloc(e, &e->dec_ids, (size_t)max_batch);
+    rc |= dmalloc(e, &e->part32, (size_t)16 * 32 * (e->qkv_dim + 48));
     rc |= dmalloc(e, &e->row_tail, T);
     rc |= dmalloc(e, &e->last_tail, (size_t)max_batch);
     rc |= dmalloc(e, &e->ones, (size_t)max_batch);
@@ -243,7 +300,7 @@ extern "C" void dh_engine_destroy(dh_engine* e) {
     if (e->gexec) hipGraphExecDestroy(e->gexec);
     void* ptrs[] = {e->kc, e->vtc, e->x, e->xn, e->qkv, e->qrot, e->att, e->xa, e->act, e->xlast, e->logits,
                     e->tok_slot, e->tok_pos, e->seq_meta, e->last_row, e->step_dev, e->dec_ids, e->dec_work,
-                    e->row_tail, e->last_tail, e->ones};
+                    e->row_tail, e->last_tail, e->ones, e->part32};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (e->h_stage) hipHostFree(e->h_stage);
@@ -324,6 +381,14 @@ extern "C" int dh_engine_forward(dh_engine* e, const int64_t* ids, const int32_t
     DH_HIP(hipMemcpyAsync(e->last_row, h_meta + 4 * B, B * sizeof(int32_t), hipMemcpyHostToDevice, s));
     int rc;
     // one token per sequence == a decode step (what generate()'s loop issues): same kernels as dh_engine_decode
+    const bool fast = max_q == 1 && n_seq <= 32 && e->d.n_embd % 16 == 0;
+    if (fast) {
+        if ((rc = run_layers_decode(e, ids, n_seq, e->row_tail, s))) return rc;
+        e->last_ntok = n_tok;
+        if (logits_all && (rc = head_normed(e, n_seq, logits_all, s))) return rc;
+        if (logits_last && (rc = head_normed(e, n_seq, logits_last, s))) return rc;
+        return 0;
+    }
     if ((rc = run_layers(e, ids, n_tok, n_seq, max_q, max_q == 1, e->row_tail, s))) return rc;
     e->last_ntok = n_tok;
     if (logits_all) {
@@ -352,8 +417,13 @@ int decode_step(dh_engine* e, int64_t* tokens, int tok_ld, int32_t* length, int3
                        e->tok_slot, e->tok_pos, kv_len, e->step_dev, n_seq, e->s_max);
     DH_LAUNCH_CHECK();
     int rc;
-    if ((rc = run_layers(e, e->dec_ids, n_seq, n_seq, 1, true, e->ones, s))) return rc;
-    if ((rc = head(e, e->x, n_seq, e->logits, e->ones, s))) return rc;
+    if (n_seq <= 32) {
+        if ((rc = run_layers_decode(e, e->dec_ids, n_seq, e->ones, s))) return rc;
+        if ((rc = head_normed(e, n_seq, e->logits, s))) return rc;
+    } else {
+        if ((rc = run_layers(e, e->dec_ids, n_seq, n_seq, 1, true, e->ones, s))) return rc;
+        if ((rc = head(e, e->x, n_seq, e->logits, e->ones, s))) return rc;
+    }
     // the per-step RNG counter lives in step_dev (incremented by decode_prep_kernel)
     return dh_sample_impl(e->logits, e->d.vocab, tokens, tok_ld, length, done, n_seq, temperature, top_k, eos_id,
                           seed, 0, e->step_dev, s);

@@ -23,17 +23,19 @@ constexpr int CH = 8;        // k-steps loaded ahead per wave
 template <int EPI, bool RESID>
 __global__ __launch_bounds__(512, 2) void gemm_skinny_kernel(GemmArgs a) {
     __shared__ __attribute__((aligned(16))) float part[NW][32][ROWS];   // [wave][m][n]
+    __shared__ __attribute__((aligned(16))) float part2[EPI == DH_EPI_SWIGLU ? NW : 1][32][ROWS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * ROWS;
     const int lrow = lane & 15, kg = lane >> 4;          // MFMA operand row / 8-element k group
-    // SWIGLU: waves 0-3 stream fc_1, waves 4-7 stream fc_2 (4-way K split each)
-    const bool second = (EPI == DH_EPI_SWIGLU) && wave >= NW / 2;
-    const int kw = (EPI == DH_EPI_SWIGLU) ? (wave & (NW / 2 - 1)) : wave;
-    const int kstride = (EPI == DH_EPI_SWIGLU) ? NW / 2 : NW;
-    const bf16_t* wbase = second ? a.w2 : a.w;
+    // SWIGLU: every wave streams its k-steps of the SAME 16 rows of fc_1 and fc_2, so one pair of
+    // x fragments feeds four MFMAs (x is the larger share of the load instructions otherwise)
+    constexpr bool SW = EPI == DH_EPI_SWIGLU;
+    constexpr int CHK = SW ? CH / 2 : CH;
+    const int kw = wave, kstride = NW;
     int n = n0 + lrow;
     n = n < a.N ? n : a.N - 1;
-    const bf16_t* wrow = wbase + (size_t)n * a.K + kg * 8;
+    const bf16_t* wrow = a.w + (size_t)n * a.K + kg * 8;
+    const bf16_t* wrow2 = SW ? a.w2 + (size_t)n * a.K + kg * 8 : nullptr;
     int m_lo = lrow, m_hi = 16 + lrow;
     m_lo = m_lo < a.M ? m_lo : a.M - 1;
     m_hi = m_hi < a.M ? m_hi : a.M - 1;
@@ -41,30 +43,40 @@ __global__ __launch_bounds__(512, 2) void gemm_skinny_kernel(GemmArgs a) {
     const bf16_t* xhi = a.x + (size_t)m_hi * a.K + kg * 8;
 
     f32x4 acc_lo = {0.f, 0.f, 0.f, 0.f}, acc_hi = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc2_lo = {0.f, 0.f, 0.f, 0.f}, acc2_hi = {0.f, 0.f, 0.f, 0.f};
     const int nks = a.K / 32;
-    for (int ks0 = kw; ks0 < nks; ks0 += kstride * CH) {
-        bf16x8 wf[CH], xl[CH], xh[CH];
+    for (int ks0 = kw; ks0 < nks; ks0 += kstride * CHK) {
+        bf16x8 wf[CHK], wf2[CHK], xl[CHK], xh[CHK];
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
+        for (int c = 0; c < CHK; ++c) {
             const int ks = ks0 + c * kstride;
             if (ks < nks) {
                 wf[c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wrow + ks * 32));
+                if (SW) wf2[c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wrow2 + ks * 32));
                 xl[c] = *reinterpret_cast<const bf16x8*>(xlo + ks * 32);
                 xh[c] = *reinterpret_cast<const bf16x8*>(xhi + ks * 32);
             }
         }
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
+        for (int c = 0; c < CHK; ++c) {
             const int ks = ks0 + c * kstride;
             if (ks < nks) {
                 acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c], xl[c], acc_lo, 0, 0, 0);
                 acc_hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c], xh[c], acc_hi, 0, 0, 0);
+                if (SW) {
+                    acc2_lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2[c], xl[c], acc2_lo, 0, 0, 0);
+                    acc2_hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2[c], xh[c], acc2_hi, 0, 0, 0);
+                }
             }
         }
     }
     // C layout: col (m) = lane & 15, rows (n) = 4*(lane>>4) + reg  -> 4 consecutive n per lane
     *reinterpret_cast<f32x4*>(&part[wave][lrow][kg * 4]) = acc_lo;
     *reinterpret_cast<f32x4*>(&part[wave][16 + lrow][kg * 4]) = acc_hi;
+    if (SW) {
+        *reinterpret_cast<f32x4*>(&part2[wave][lrow][kg * 4]) = acc2_lo;
+        *reinterpret_cast<f32x4*>(&part2[wave][16 + lrow][kg * 4]) = acc2_hi;
+    }
     __syncthreads();
 
     const int tn = tid & 15, tm = tid >> 4;
@@ -74,10 +86,11 @@ __global__ __launch_bounds__(512, 2) void gemm_skinny_kernel(GemmArgs a) {
     float o;
     if (EPI == DH_EPI_SWIGLU) {
         float g = 0.f, u = 0.f;
+        const float* p2 = &part2[0][0][0] + tm * ROWS + tn;
 #pragma unroll
-        for (int w = 0; w < NW / 2; ++w) {
+        for (int w = 0; w < NW; ++w) {
             g += p[w * 32 * ROWS];
-            u += p[(w + NW / 2) * 32 * ROWS];
+            u += p2[w * 32 * ROWS];
         }
         g = rbf(g);
         u = rbf(u);
@@ -108,6 +121,117 @@ __global__ __launch_bounds__(512, 2) void gemm_skinny_kernel(GemmArgs a) {
     a.y[(size_t)tm * a.N + nn] = f2bf(o);
 }
 
+// fp32 partial sums for consumers that finish the epilogue themselves (decode_fused.hip):
+//   part[by][m][n] = sum over the k-steps of K-slice `by` of x[m,:] . W'[n,:],  W' = [w ; w_ext]
+// grid (N'/16, ksplit): the 8*ksplit waves that share a row tile interleave over K, so small
+// matrices (N = d) still put >= 256 blocks on the chip.
+__global__ __launch_bounds__(512, 2) void gemm_skinny_partial_kernel(const bf16_t* __restrict__ x,
+                                                                   const bf16_t* __restrict__ w,
+                                                                   const bf16_t* __restrict__ w_ext,
+                                                                   float* __restrict__ y32, int M, int n_main,
+                                                                   int N, int K) {
+    __shared__ __attribute__((aligned(16))) float part[NW][32][ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * ROWS, ksplit = gridDim.y;
+    const int lrow = lane & 15, kg = lane >> 4;
+    int n = n0 + lrow;
+    n = n < N ? n : N - 1;
+    const bf16_t* wrow = (n < n_main ? w + (size_t)n * K : w_ext + (size_t)(n - n_main) * K) + kg * 8;
+    int m_lo = lrow, m_hi = 16 + lrow;
+    m_lo = m_lo < M ? m_lo : M - 1;
+    m_hi = m_hi < M ? m_hi : M - 1;
+    const bf16_t* xlo = x + (size_t)m_lo * K + kg * 8;
+    const bf16_t* xhi = x + (size_t)m_hi * K + kg * 8;
+    f32x4 acc_lo = {0.f, 0.f, 0.f, 0.f}, acc_hi = {0.f, 0.f, 0.f, 0.f};
+    const int nks = K / 32, kstride = NW * ksplit;
+    for (int ks0 = blockIdx.y * NW + wave; ks0 < nks; ks0 += kstride * CH) {
+        bf16x8 wf[CH], xl[CH], xh[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int ks = ks0 + c * kstride;
+            if (ks < nks) {
+                wf[c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wrow + ks * 32));
+                xl[c] = *reinterpret_cast<const bf16x8*>(xlo + ks * 32);
+                xh[c] = *reinterpret_cast<const bf16x8*>(xhi + ks * 32);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int ks = ks0 + c * kstride;
+            if (ks < nks) {
+                acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c], xl[c], acc_lo, 0, 0, 0);
+                acc_hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c], xh[c], acc_hi, 0, 0, 0);
+            }
+        }
+    }
+    *reinterpret_cast<f32x4*>(&part[wave][lrow][kg * 4]) = acc_lo;
+    *reinterpret_cast<f32x4*>(&part[wave][16 + lrow][kg * 4]) = acc_hi;
+    __syncthreads();
+    const int tn = tid & 15, tm = tid >> 4, nn = n0 + tn;
+    if (tm >= M || nn >= N) return;
+    const float* p = &part[0][0][0] + tm * ROWS + tn;
+    float s = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < NW; ++wv) s += p[wv * 32 * ROWS];
+    y32[((size_t)blockIdx.y * M + tm) * N + nn] = s;
+}
+
+// Row-parallel variant: the 8 waves of a block own 16 W rows EACH (128 rows per block) and all
+// work on the SAME K-slice, so the x slice [32 x 32*KPS] is staged once per block in LDS (x is
+// 2/3 of the load instructions when every wave fetches its own fragments) and no cross-wave
+// reduction is needed: each wave stores its fp32 tile straight from the accumulators.
+//   grid (ceil(N/128), ksplit), K-slice = KPS k-steps of 32.
+template <int KPS>
+__global__ __launch_bounds__(512, 2) void gemm_skinny_rows_kernel(const bf16_t* __restrict__ x,
+                                                                const bf16_t* __restrict__ w,
+                                                                const bf16_t* __restrict__ w_ext,
+                                                                float* __restrict__ y32, int M, int n_main, int N,
+                                                                int K) {
+    constexpr int XS = KPS * 64 + 16;                      // padded row stride of the x slice (bytes)
+    __shared__ __attribute__((aligned(16))) char sx[32 * XS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 15, kg = lane >> 4;
+    const int n0 = blockIdx.x * 128 + wave * 16;
+    const int nks = K / 32;
+    const int ks_begin = blockIdx.y * KPS;
+    const int ks_cnt = min(KPS, nks - ks_begin);          // >= 1 by construction of the grid
+    int n = n0 + lrow;
+    n = n < N ? n : N - 1;
+    const bf16_t* wrow = (n < n_main ? w + (size_t)n * K : w_ext + (size_t)(n - n_main) * K) + ks_begin * 32 + kg * 8;
+    bf16x8 wf[KPS];
+#pragma unroll
+    for (int c = 0; c < KPS; ++c)
+        if (c < ks_cnt) wf[c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wrow + c * 32));
+    // stage the x slice: 32 rows x ks_cnt*4 chunks of 16 B
+    for (int c = tid; c < 32 * KPS * 4; c += 512) {
+        const int row = c / (KPS * 4), col = c % (KPS * 4);
+        if (col < ks_cnt * 4) {
+            const int m = row < M ? row : M - 1;
+            *reinterpret_cast<uint4*>(sx + row * XS + col * 16) =
+                *reinterpret_cast<const uint4*>(x + (size_t)m * K + ks_begin * 32 + col * 8);
+        }
+    }
+    __syncthreads();
+    f32x4 acc_lo = {0.f, 0.f, 0.f, 0.f}, acc_hi = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < KPS; ++c) {
+        if (c < ks_cnt) {
+            const bf16x8 xl = *reinterpret_cast<const bf16x8*>(sx + lrow * XS + c * 64 + kg * 16);
+            const bf16x8 xh = *reinterpret_cast<const bf16x8*>(sx + (16 + lrow) * XS + c * 64 + kg * 16);
+            acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c], xl, acc_lo, 0, 0, 0);
+            acc_hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c], xh, acc_hi, 0, 0, 0);
+        }
+    }
+    const int nn = n0 + kg * 4;
+    if (nn < N) {
+        float* out = y32 + (size_t)blockIdx.y * M * N + nn;
+        if (lrow < M) *reinterpret_cast<f32x4*>(out + (size_t)lrow * N) = acc_lo;
+        if (16 + lrow < M) *reinterpret_cast<f32x4*>(out + (size_t)(16 + lrow) * N) = acc_hi;
+    }
+}
+
+int g_skinny_variant = 1;   // 0: K split over the waves of a block, 1: row-parallel with LDS-staged x
+
 template <int EPI>
 int launch(const GemmArgs& a, hipStream_t s) {
     dim3 grid(cdiv(a.N, ROWS)), block(512);
@@ -120,6 +244,39 @@ int launch(const GemmArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int dh_linear_partial_bf16(const dh_bf16* x, const dh_bf16* w, const dh_bf16* w_ext, float* y32, int M,
+                                      int n_main, int n_ext, int K, int ksplit, void* stream) {
+    DH_CHECK(x && w && y32 && M >= 1 && M <= 32, "dh_linear_partial_bf16: need 1 <= M <= 32 (got %d)", M);
+    DH_CHECK(K % 32 == 0 && n_main % ROWS == 0 && n_ext % ROWS == 0 && n_main > 0 && n_ext >= 0,
+             "dh_linear_partial_bf16: K %% 32 and row counts %% 16 must be 0");
+    DH_CHECK(n_ext == 0 || w_ext, "dh_linear_partial_bf16: null w_ext");
+    DH_CHECK(ksplit >= 1 && ksplit <= 16, "dh_linear_partial_bf16: ksplit must be 1..16");
+    const int N = n_main + n_ext;
+    const int nks = K / 32;
+    const int kps = (nks + ksplit - 1) / ksplit;
+    if (g_skinny_variant == 1 && (kps == 8 || kps == 16) && (ksplit - 1) * kps < nks && N % 4 == 0) {
+        dim3 grid((N + 127) / 128, ksplit), block(512);
+        if (kps == 8)
+            hipLaunchKernelGGL((gemm_skinny_rows_kernel<8>), grid, block, 0, (hipStream_t)stream, x, w, w_ext ? w_ext : w,
+                               y32, M, n_main, N, K);
+        else
+            hipLaunchKernelGGL((gemm_skinny_rows_kernel<16>), grid, block, 0, (hipStream_t)stream, x, w, w_ext ? w_ext : w,
+                               y32, M, n_main, N, K);
+    } else {
+        DH_CHECK(ksplit <= 8, "dh_linear_partial_bf16: ksplit must be 1..8 for this shape");
+        hipLaunchKernelGGL(gemm_skinny_partial_kernel, dim3(N / ROWS, ksplit), dim3(512), 0, (hipStream_t)stream, x, w,
+                           w_ext ? w_ext : w, y32, M, n_main, N, K);
+    }
+    DH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dh_set_tuning(int key, int value) {
+    if (key == 0) { g_skinny_variant = value; return 0; }
+    dh_set_error("dh_set_tuning: unknown key %d", key);
+    return 1;
+}
 
 int dh_linear_skinny(const GemmArgs& a, int epilogue, hipStream_t s) {
     switch (epilogue) {

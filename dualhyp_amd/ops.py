@@ -136,3 +136,57 @@ def sample(logits: torch.Tensor, tokens: torch.Tensor, length: torch.Tensor, don
                                      _p(_dev(done, torch.int32)), n_seq, float(temperature),
                                      0 if top_k is None else int(top_k), -1 if eos_id is None else int(eos_id),
                                      int(seed) & ((1 << 64) - 1), int(step), _stream()))
+
+
+def linear_partial(x: torch.Tensor, w: torch.Tensor, w_ext: Optional[torch.Tensor] = None, ksplit: int = 1) -> torch.Tensor:
+    """fp32 partial sums [ksplit, M, n_main+n_ext] of x @ [w; w_ext].T (M <= 32); dh_linear_partial_bf16."""
+    x, w = _dev(x, name="x"), _dev(w, name="w")
+    K = x.size(-1)
+    M = x.numel() // K
+    n_ext = 0 if w_ext is None else _dev(w_ext, name="w_ext").size(0)
+    y = torch.empty((ksplit, M, w.size(0) + n_ext), dtype=torch.float32, device=x.device)
+    check(_lib.load().dh_linear_partial_bf16(_p(x), _p(w), _p(w_ext), _p(y), M, w.size(0), n_ext, K, ksplit, _stream()))
+    return y
+
+
+def finish_norm(h32: torch.Tensor, d: int, x_resid: torch.Tensor, w_norm: torch.Tensor, eps: float,
+                lora_b: Optional[torch.Tensor] = None, lora_scale: float = 1.0,
+                row_tail: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(x_out, xn_out) = LoRA finish + residual + RMSNorm of fp32 partials; dh_finish_norm_bf16."""
+    n_part, rows, ld = h32.shape
+    x_resid = _dev(x_resid, name="x_resid")
+    x_out, xn_out = torch.empty_like(x_resid), torch.empty_like(x_resid)
+    check(_lib.load().dh_finish_norm_bf16(_p(h32), n_part, rows, d, ld - d, _p(lora_b), float(lora_scale), _p(x_resid),
+                                          _p(_dev(w_norm)), _p(x_out), _p(xn_out), float(eps), _p(row_tail), _stream()))
+    return x_out, xn_out
+
+
+def attn_decode_fused(qkv32: torch.Tensor, qkv_dim: int, lora_b: Optional[torch.Tensor], lora_scale: float,
+                      splits: Tuple[int, int], cos: torch.Tensor, sin: torch.Tensor, seq_slot: torch.Tensor,
+                      kv_len: torch.Tensor, k_cache: torch.Tensor, vT_cache: torch.Tensor, n_head: int) -> torch.Tensor:
+    """Decode-step attention sub-layer from fp32 qkv partials; dh_attn_decode_fused_bf16."""
+    n_part, n_seq, ld = qkv32.shape
+    n_groups, s_max, hs = k_cache.size(1), k_cache.size(2), k_cache.size(3)
+    y = torch.empty((n_seq, n_head * hs), dtype=torch.bfloat16, device=qkv32.device)
+    i32 = torch.int32
+    check(_lib.load().dh_attn_decode_fused_bf16(_p(qkv32), n_part, n_seq, qkv_dim, ld - qkv_dim, _p(lora_b),
+                                                float(lora_scale), splits[0], splits[1], _p(_dev(cos)), _p(_dev(sin)),
+                                                _p(_dev(seq_slot, i32)), _p(_dev(kv_len, i32)), _p(k_cache), _p(vT_cache),
+                                                _p(y), n_head, n_groups, hs, s_max, _stream()))
+    return y
+
+
+def kcache_to_plain(kc: torch.Tensor) -> torch.Tensor:
+    """K cache [slot, group, s_max, hs] as stored (MFMA-fragment order, csrc/common.h kfrag_off)
+    -> plain [slot, group, key, channel].  Test/debug helper."""
+    B, G, S, hs = kc.shape
+    v = kc.reshape(B, G, S // 32, hs // 16, 2, 32, 8)            # tile, ks, lh, lr, e
+    return v.permute(0, 1, 2, 5, 3, 4, 6).reshape(B, G, S, hs)
+
+
+def vcache_to_plain(vt: torch.Tensor) -> torch.Tensor:
+    """V^T cache [slot, group, hs, s_max] as stored (fragment order, vfrag_off) -> plain
+    [slot, group, channel, key].  Test/debug helper."""
+    B, G, hs, S = vt.shape
+    v = vt.reshape(B, G, S // 32, hs // 32, 2, 2, 32, 2, 4)      # tile, dt, s2, lh, lr, jh, jl
+    return v.permute(0, 1, 3, 6, 2, 4, 7, 5, 8).reshape(B, G, hs, S)

@@ -29,6 +29,9 @@ typedef uint16_t dh_bf16;
 #define DH_ABI_VERSION 1
 
 int dh_abi_version(void);
+/* Kernel-variant selector for benchmarking (key 0: decode partial-sum GEMM, 0 = K split over the
+ * waves of a block, 1 = row-parallel with the x slice staged in LDS).  Not needed in production. */
+int dh_set_tuning(int key, int value);
 const char* dh_last_error(void);
 /* Name of the first visible device's gcnArch ("gfx950") into buf; fails when no GPU. */
 int dh_device_info(char* h_buf, int h_buf_len, int* h_num_cu, int64_t* h_hbm_bytes);
@@ -87,6 +90,24 @@ int dh_linear_bf16(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N,
                    const dh_bf16* vec_a, const dh_bf16* vec_b, const dh_bf16* resid,
                    void* stream);
 
+/* fp32 partial sums for the fused decode consumers below (M <= 32, weight streaming):
+ *   y32[p][m][n] = sum over K-slice p of x[m,:] . W'[n,:],  W' = [w (n_main rows) ; w_ext (n_ext rows)]
+ * y32: [ksplit][M][n_main+n_ext] fp32.  w_ext is the rank-padded LoRA A (so x·A^T comes out of the
+ * same pass over x as x·W^T and never needs its own launch).  K %% 32 == 0, rows %% 16 == 0. */
+int dh_linear_partial_bf16(const dh_bf16* x, const dh_bf16* w, const dh_bf16* w_ext, float* y32,
+                           int M, int n_main, int n_ext, int K, int ksplit, void* stream);
+
+/* LoRA finish + residual add + RMSNorm of one decode row block — ger/lora.py:159-166,
+ * ger/model.py:185-186, ger/rmsnorm.py:17-21 in one pass:
+ *   h = bf16(bf16(sum_p h32[p]) + bf16(bf16(xa . B^T) * s)) ; x_out = bf16(x_resid + h) ;
+ *   xn_out = RMSNorm(x_out; w_norm, eps)      (row_tail: see dh_rmsnorm_bf16)
+ * h32: [n_part][rows][d+n_ext] fp32 from dh_linear_partial_bf16, xa = bf16 of columns [d, d+16).
+ * lora_b == NULL: no LoRA (n_ext = 0).  x_out may alias x_resid. */
+int dh_finish_norm_bf16(const float* h32, int n_part, int rows, int d, int n_ext,
+                        const dh_bf16* lora_b, float lora_scale, const dh_bf16* x_resid,
+                        const dh_bf16* w_norm, dh_bf16* x_out, dh_bf16* xn_out, float eps,
+                        const uint8_t* row_tail, void* stream);
+
 /* ------------------------------------------------------------------ attention */
 
 /* Causal attention of a packed batch against the KV cache — ger/model.py:261,270-290 with the
@@ -104,6 +125,18 @@ int64_t dh_attn_decode_work_bytes(int n_seq, int n_head, int hs, int s_max);
 int dh_attn_decode_bf16(const dh_bf16* q, const dh_bf16* k_cache, const dh_bf16* vT_cache,
                         const int32_t* seq_slot, const int32_t* kv_len, dh_bf16* y, void* work,
                         int n_seq, int n_head, int n_groups, int hs, int s_max, void* stream);
+
+/* The whole attention sub-layer of a decode step in one launch — ger/model.py:216-261 for T = 1:
+ * finish the q/k/v LoRA from the fp32 partials of dh_linear_partial_bf16 (columns
+ * [qkv_dim, qkv_dim+48) = x.A^T; contiguous [Q|K|V] delta, quirk Q2), rotate q and k at position
+ * kv_len-1, append k / v to the caches, attend keys 0..kv_len-1 (split over 8 waves, combined in
+ * LDS; the new key is merged from registers), write y [n_seq, n_head*hs]. */
+int dh_attn_decode_fused_bf16(const float* qkv32, int n_part, int n_seq, int qkv_dim, int n_ext,
+                              const dh_bf16* lora_b, float lora_scale, int split0, int split1,
+                              const dh_bf16* cos, const dh_bf16* sin, const int32_t* seq_slot,
+                              const int32_t* kv_len, dh_bf16* k_cache, dh_bf16* vT_cache,
+                              dh_bf16* y, int n_head, int n_groups, int hs, int s_max,
+                              void* stream);
 
 /* ------------------------------------------------------------------ token sampling */
 
