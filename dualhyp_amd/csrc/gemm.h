@@ -22,6 +22,10 @@ struct GemmArgs {
 // M <= 32: one pass over W straight from HBM to registers (gemm_skinny.hip)
 int dh_linear_skinny(const GemmArgs& a, int epilogue, hipStream_t s);
 
+// M >= 256: 256 x 256 x 64 tiles, one block per CU (gemm256.hip)
+int dh_linear_256(GemmArgs a, int epilogue, hipStream_t s);
+extern int g_gemm_variant;   // 1: use the 256-tile kernel when the shape allows, 0: always 128-tile
+
 // dh_linear_bf16 with an explicit kernel choice.  kernel: 0 = by shape (M <= 32 -> skinny),
 // 1 = tiled MFMA kernel whatever M.  The engine pins the choice per PHASE (prefill = tiled,
 // single-token decode = skinny) so a sequence's result never depends on how many other

@@ -213,6 +213,8 @@ int launch(const GemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
+int g_gemm_variant = 1;
+
 extern "C" int dh_linear_bf16(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N, int K, int epilogue,
                               const dh_bf16* w2, const dh_bf16* xa, int xa_ld, const dh_bf16* lora_b,
                               float lora_scale, int split0, int split1, const dh_bf16* vec_a,
@@ -237,6 +239,18 @@ int dh_linear_impl(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N,
     a.nb_m = cdiv(M, BT);
     a.nb_n = (epilogue == DH_EPI_SWIGLU) ? cdiv(N, 64) : cdiv(N, BT);
     const bool skinny = kernel == 0 && M <= 32 && K % 32 == 0;   // weight-streaming kernel (gemm_skinny.hip)
+    const bool big = !skinny && g_gemm_variant >= 1 && M >= 256 && N >= (epilogue == DH_EPI_SWIGLU ? 128 : 256);
+    if (big) {
+        if (epilogue == DH_EPI_LORA) {
+            DH_CHECK(xa && lora_b && xa_ld >= 16 && xa_ld % 8 == 0, "dh_linear_bf16: LORA epilogue needs xa/lora_b");
+            DH_CHECK(split0 % 32 == 0 && split1 % 32 == 0 && split0 <= split1, "dh_linear_bf16: LoRA splits must be multiples of 32");
+            DH_CHECK(xa_ld >= 16 * (1 + (split0 < N) + (split1 < N)), "dh_linear_bf16: xa_ld too small for the segments");
+        }
+        if (epilogue == DH_EPI_SWIGLU) DH_CHECK(w2 != nullptr && resid == nullptr && N % 32 == 0, "dh_linear_bf16: bad SWIGLU arguments");
+        if (epilogue == DH_EPI_ADAPTER) DH_CHECK(vec_a && vec_b, "dh_linear_bf16: ADAPTER epilogue needs scale/bias vectors");
+        DH_CHECK(epilogue >= 0 && epilogue <= 3, "dh_linear_bf16: unknown epilogue %d", epilogue);
+        return dh_linear_256(a, epilogue, s);
+    }
     switch (epilogue) {
         case DH_EPI_PLAIN:
             return skinny ? dh_linear_skinny(a, epilogue, s) : launch<DH_EPI_PLAIN>(a, s);

@@ -274,6 +274,7 @@ extern "C" int dh_linear_partial_bf16(const dh_bf16* x, const dh_bf16* w, const 
 
 extern "C" int dh_set_tuning(int key, int value) {
     if (key == 0) { g_skinny_variant = value; return 0; }
+    if (key == 1) { g_gemm_variant = value; return 0; }
     dh_set_error("dh_set_tuning: unknown key %d", key);
     return 1;
 }

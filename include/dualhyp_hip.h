@@ -30,7 +30,8 @@ typedef uint16_t dh_bf16;
 
 int dh_abi_version(void);
 /* Kernel-variant selector for benchmarking (key 0: decode partial-sum GEMM, 0 = K split over the
- * waves of a block, 1 = row-parallel with the x slice staged in LDS).  Not needed in production. */
+ * waves of a block, 1 = row-parallel with the x slice staged in LDS; key 1: prefill GEMM, 0 = always
+ * 128x128 tiles, 1 = 256x256 tiles when M >= 256).  Not needed in production. */
 int dh_set_tuning(int key, int value);
 const char* dh_last_error(void);
 /* Name of the first visible device's gcnArch ("gfx950") into buf; fails when no GPU. */

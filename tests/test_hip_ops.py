@@ -74,7 +74,7 @@ def test_linear_plain_and_resid(dev, M, N, K):
     check_ulp(ops.linear(x.to(dev), w.to(dev), resid=r.to(dev)), r + want, 2, 0.002, "linear+resid")
 
 
-@pytest.mark.parametrize("M,d,r", [(70, 256, 4), (130, 2048, 16)])
+@pytest.mark.parametrize("M,d,r", [(70, 256, 4), (130, 2048, 16), (300, 256, 4), (517, 2048, 16)])
 def test_linear_lora(dev, M, d, r):
     """ger/lora.py:159-166 (proj) and :367-402 (qkv, contiguous [Q|K|V] delta, quirk Q2)."""
     from dualhyp_amd import ops
@@ -106,7 +106,7 @@ def test_linear_lora(dev, M, d, r):
     check_ulp(got, want, 2, 0.002, "proj lora + resid")
 
 
-@pytest.mark.parametrize("M,d,I", [(50, 256, 384), (200, 2048, 5632)])
+@pytest.mark.parametrize("M,d,I", [(50, 256, 384), (200, 2048, 5632), (300, 256, 384), (515, 2048, 5632)])
 def test_linear_swiglu_and_adapter(dev, M, d, I):
     from dualhyp_amd import ops
     x, w1, w2 = U((M, d), 1.0, "sx"), U((I, d), 0.05, "s1"), U((I, d), 0.05, "s2")
