@@ -19,6 +19,7 @@ struct GemmArgs {
 };
 
 
+
 // M <= 32: one pass over W straight from HBM to registers (gemm_skinny.hip)
 int dh_linear_skinny(const GemmArgs& a, int epilogue, hipStream_t s);
 

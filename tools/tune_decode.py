@@ -43,8 +43,13 @@ for variant in (0, 1):
     for ks in ((1, 2, 4) if variant == 0 else (11,)):
         t = bench(lambda i: ops.linear_partial(xa, Wm[i % L], None, ksplit=ks))
         print(f"variant {variant} mlp ks={ks}: {t:6.1f} us  {d*I*2/t/1e6:5.2f} TB/s")
+Wl = [torch.randn(32000, d, device=D).bfloat16() * 0.02 for _ in range(3)]
+sc = torch.ones(32000, device=D).bfloat16(); bi = torch.zeros(32000, device=D).bfloat16()
 t = bench(lambda i: ops.linear(x, W1[i % L], epilogue=ops.EPI_SWIGLU, w2=W2[i % L]))
 print(f"swiglu: {t:6.1f} us  {2*I*d*2/t/1e6:5.2f} TB/s")
+t = bench(lambda i: ops.linear(x, Wl[i % 3], epilogue=ops.EPI_ADAPTER, scale=sc, bias=bi))
+print(f"lm_head: {t:6.1f} us  {32000*d*2/t/1e6:5.2f} TB/s")
+
 t = bench(lambda i: ops.linear(x, Wq[i % L]))
 print(f"plain skinny qkv: {t:6.1f} us  {2560*d*2/t/1e6:5.2f} TB/s")
 y32 = ops.linear_partial(x, Wp[0], A16[0], ksplit=2)
