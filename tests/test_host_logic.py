@@ -1,0 +1,144 @@
+"""CPU tests of the host-side logic either side of the decoder: prompt packing, labels, collate,
+reliability tokens, WER, utterance sharding + counter all-reduce over gloo (world_size 2)."""
+import json
+import os
+import socket
+from pathlib import Path
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from dualhyp_amd import data as D
+from dualhyp_amd.inference import extract_answer, run_inference, shard_indices
+from dualhyp_amd.wer import edit_counts, post_normalize, wer, wer_counts
+
+GOLDEN = Path(__file__).parent / "golden"
+
+
+class CharTok:
+    """Stand-in tokenizer (no HF tokenizer offline): BOS + one id per character."""
+    eos_token = "\x03"
+
+    def encode(self, s):
+        return [1] + [ord(c) + 3 for c in s]
+
+    def decode(self, ids):
+        return "".join(chr(int(i) - 3) for i in ids if int(i) > 3)
+
+
+def sample(uid="u1", snr=-5):
+    return {"Uid": uid, "Caption": "the cat sat", "Dataset": "LRS2",
+            "nhyps_asr": {"hyps": ["the cat sat", "the cat sad", "a cat sat", "the bat sat", "the cat set"], "scores": [0] * 5},
+            "nhyps_vsr": {"hyps": ["the cap sat", "the cat sat", "the gap sat", "the cab sat", "he cat sat"], "scores": [0] * 5},
+            "Audio_Corruption": {"total_len": 32000, "start_fr": 8000, "occ_len": 2000, "snr": snr, "noise_name": "babble"},
+            "Visual_Corruption": {"total_len": 50, "start_fr": 20, "occ_len": 12}}
+
+
+def test_templates_equal_the_reference():
+    ref = json.loads((GOLDEN / "prompts.json").read_text())["prompts"]   # dumped from data/prompts.py by make_golden.py
+    for name in ("GER", "DualHyp", "RelPrompt"):
+        assert D.get_prompts_format(name) == ref[name]
+    with pytest.raises(ValueError):
+        D.get_prompts_format("nope")
+
+
+def test_prompt_strings():
+    s = sample()
+    g = D.ger_prompt(s)
+    assert g.endswith("### Best-hypothesis:\nthe cat sat\n\n### Other-hypothesis:\nthe cat sad\na cat sat\nthe bat sat\nthe cat set\n\n### Response:\n")
+    d = D.dualhyp_prompt(s, s)
+    assert "### ASR Best-hypothesis:\nthe cat sat\n\n### VSR Best-hypothesis:\nthe cap sat\n\n### ASR Other-hypotheses:\nthe cat sad\n" in d
+    assert d.endswith("### VSR Other-hypotheses:\nthe cat sat\nthe gap sat\nthe cab sat\nhe cat sat\n\n### Response:\n")
+    assert D.dualhyp_prompt(s, s, max_nhyps=3).count("\n") < d.count("\n")
+    # reliability tokens: 0.4 s chunks = 6400 samples / 10 frames (data/av_dataset.py:444-445)
+    am = D.noise_mask(s, "audio")
+    assert am.count("N") == 2000 and am[8000] == "N" and am[7999] == "C"
+    scores, labels = D.chunk_reliability(am, 6400)
+    assert labels == ["<<C>>", "<<M>>", "<<C>>", "<<C>>", "<<C>>"] and abs(scores[1] - 4400 / 6400) < 1e-9
+    assert D.noise_mask(sample(snr=10), "audio", mask_threshold=0).count("N") == 0          # snr above threshold: clean
+    _, vl = D.chunk_reliability(D.noise_mask(s, "video"), 10)
+    assert vl == ["<<C>>", "<<C>>", "<<N>>", "<<M>>", "<<C>>"]
+    r = D.relprompt_prompt(s, s, labels, vl)
+    assert "### Audio Mask:\n<<C>><<M>><<C>><<C>><<C>>\n\n\n### VSR Best-hypothesis:\nthe cap sat" in r and r.endswith("\n\n\n### Response:\n")
+
+
+def test_encode_collate_and_dataset():
+    tok = CharTok()
+    s = sample()
+    p = D.dualhyp_prompt(s, s)
+    ex = D.encode_example(tok, p, s["Caption"])
+    n_prompt = ex["input_ids_no_response"].numel()
+    assert (ex["labels"][:n_prompt] == -1).all() and torch.equal(ex["labels"][n_prompt:], ex["input_ids"][n_prompt:])
+    assert ex["input_ids"].numel() == n_prompt + len(s["Caption"]) + 1 and ex["input"].endswith(tok.eos_token)
+    short = D.encode_example(tok, p, s["Caption"], max_input_length=50)
+    assert short["input_ids"].numel() == 50 and short["labels"].numel() == 50
+    ex2 = D.encode_example(tok, D.ger_prompt(s), s["Caption"])
+    b = D.collate([ex, ex2])
+    n = max(ex["input_ids"].numel(), ex2["input_ids"].numel())
+    assert b["input_ids"].shape == (2, n) and (b["labels"][1, ex2["labels"].numel():] == -1).all()
+    assert (b["input_ids"][1, ex2["input_ids"].numel():] == 0).all()
+    ds = D.HypothesesDataset([sample("a"), sample("a", snr=3), sample("b")], tok, "RelPrompt", seed=0)
+    assert len(ds) == 2 and ds[0]["uid"] == "a" and "<<" in ds[1]["input_no_response"]
+
+
+def test_wer_known_answers():
+    assert edit_counts("a b c".split(), "a b c".split()) == (0, 0, 0)
+    assert edit_counts("a b c".split(), "a x c".split()) == (1, 0, 0)
+    assert edit_counts("a b c".split(), "a c".split()) == (0, 1, 0)
+    assert edit_counts("a c".split(), "a b c".split()) == (0, 0, 1)
+    assert sum(edit_counts("the cat sat on the mat".split(), "cat sat on a mat today".split())) == 3
+    # corpus level: total errors / total reference words, NOT the mean of per-utterance rates
+    assert abs(wer(["a b c d", "x"], ["a b c d", "y z"]) - 2 / 6) < 1e-12
+    assert wer_counts(["hello  world "], ["hello world"])["errors"] == 0          # whitespace collapsed
+    assert post_normalize("It's A-OK, right?") == "its aok right"
+    assert extract_answer("PROMPT the cat sat\nextra line", "PROMPT ") == "the cat sat"
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    exs, gen, dec = _toy_corpus()
+    out = run_inference(gen, exs, dec, batch_size=3, rank=rank, world=world)
+    q.put((rank, {k: v for k, v in out.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _toy_corpus():
+    tok = CharTok()
+    refs = ["the cat sat", "a dog ran", "birds fly high", "no way", "yes sir", "so it goes", "ok"]
+    hyps = ["the cat sat", "a dog run", "birds fly", "no way", "yes sir yes", "so it goes", "okay"]
+    exs = [{"input_ids_no_response": torch.tensor(tok.encode(f"P{i}: ")), "ground_truth": r} for i, r in enumerate(refs)]
+
+    def gen(prompts):   # deterministic stub "model": appends the canned hypothesis of that prompt
+        outs = []
+        for p in prompts:
+            i = int(tok.decode(p)[1])
+            outs.append(torch.cat([p, torch.tensor(tok.encode(hyps[i] + "\nignored"))[1:]]))
+        return outs
+    return exs, gen, tok.decode
+
+
+def test_sharded_inference_matches_single_process():
+    assert shard_indices(7, 0, 2) == [0, 2, 4, 6] and shard_indices(7, 1, 2) == [1, 3, 5]
+    exs, gen, dec = _toy_corpus()
+    single = run_inference(gen, exs, dec, batch_size=4)
+    assert single["n"] == 7 and abs(single["WER"] - 4 / 17) < 1e-12 and abs(single["gtms"] - 3 / 7) < 1e-12
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        for k in ("WER", "gtms", "post_ST_wer", "post_gtms", "n"):
+            assert got[r][k] == single[k], (r, k)
+    assert got[0]["predictions"] == single["predictions"] and got[1]["predictions"] is None
