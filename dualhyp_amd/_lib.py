@@ -38,12 +38,19 @@ SIGNATURES = {
     "dh_device_info": (I, [C.c_char_p, I, C.POINTER(I), C.POINTER(I64)]),
     "dh_embed_bf16": (I, [P, P, P, I, I, I, P]),
     "dh_rmsnorm_bf16": (I, [P, P, P, P, P, I, I, F, P, P]),
-    "dh_qkv_rope_cache_bf16": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
+    "dh_qkv_rope_cache_bf16": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "dh_linear_bf16": (I, [P, P, P, I, I, I, I, P, P, I, P, F, I, I, P, P, P, P]),
     "dh_linear_partial_bf16": (I, [P, P, P, P, I, I, I, I, I, P]),
     "dh_finish_norm_bf16": (I, [P, I, I, I, I, P, F, P, P, P, P, F, P, P]),
     "dh_attn_decode_fused_bf16": (I, [P, I, I, I, I, P, F, I, I, P, P, P, P, P, P, P, I, I, I, I, P]),
-    "dh_attn_prefill_bf16": (I, [P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
+    "dh_attn_prefill_bf16": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
+    "dh_swiglu_bwd_bf16": (I, [P, P, P, P, I, I, P]),
+    "dh_rmsnorm_bwd_bf16": (I, [P, P, P, P, P, I, I, F, P]),
+    "dh_qkv_rope_bwd_bf16": (I, [P, P, P, P, P, P, P, I, I, I, I, P]),
+    "dh_tn_accum_f32": (I, [P, I, P, I, P, I, I, I, I, F, I, P]),
+    "dh_rowdot_f32": (I, [P, P, P, I64, I, P]),
+    "dh_transpose_pad_bf16": (I, [P, P, P, P, P, I, I, I, I, P]),
+    "dh_attn_bwd_bf16": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "dh_attn_decode_work_bytes": (I64, [I, I, I, I]),
     "dh_attn_decode_bf16": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "dh_sample_bf16": (I, [P, I, P, I, P, P, I, F, I, I64, U64, I, P]),

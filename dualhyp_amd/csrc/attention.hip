@@ -30,7 +30,8 @@ template <int HS>
 __global__ __launch_bounds__(HS == 64 ? 1024 : 512) void attn_prefill_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k_cache, const bf16_t* __restrict__ vT_cache,
     const int32_t* __restrict__ seq_slot, const int32_t* __restrict__ q_start, const int32_t* __restrict__ q_len,
-    const int32_t* __restrict__ kv_pos0, bf16_t* __restrict__ y, int n_head, int n_groups, int s_max, float scale) {
+    const int32_t* __restrict__ kv_pos0, bf16_t* __restrict__ y, float* __restrict__ lse, int n_head, int n_groups,
+    int s_max, float scale) {
     constexpr int KS = HS / 16;   // k-steps of the QK product
     constexpr int DT = HS / 32;   // 32-row tiles of O^T
     constexpr int TILE_B = HS * 32 * 2;   // bytes of one 32-key tile of K (and of V^T)
@@ -149,6 +150,8 @@ __global__ __launch_bounds__(HS == 64 ? 1024 : 512) void attn_prefill_kernel(
     // ---- normalise and store y[q][head*HS + d]
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
+    if (lse != nullptr && lh == 0 && q0 + lr < qlen)     // log-sum-exp of the scaled scores (training backward)
+        lse[(size_t)(qs + q0 + lr) * n_head + head] = m_run + logf(l_tot);
     if (q0 + lr < qlen) {
         bf16_t* yp = y + (size_t)(qs + q0 + lr) * n_head * HS + head * HS;
 #pragma unroll
@@ -306,8 +309,8 @@ constexpr int DEC_NSPLIT = 4;
 
 extern "C" int dh_attn_prefill_bf16(const dh_bf16* q, const dh_bf16* k_cache, const dh_bf16* vT_cache,
                                     const int32_t* seq_slot, const int32_t* q_start, const int32_t* q_len,
-                                    const int32_t* kv_pos0, dh_bf16* y, int n_seq, int max_q_len, int n_head,
-                                    int n_groups, int hs, int s_max, void* stream) {
+                                    const int32_t* kv_pos0, dh_bf16* y, float* lse, int n_seq, int max_q_len,
+                                    int n_head, int n_groups, int hs, int s_max, void* stream) {
     DH_CHECK(n_groups > 0 && n_head % n_groups == 0 && n_head / n_groups <= 16, "dh_attn_prefill_bf16: bad head counts");
     DH_CHECK(hs == 64 || hs == 128, "dh_attn_prefill_bf16: head_size %d unsupported", hs);
     DH_CHECK(s_max % 64 == 0, "dh_attn_prefill_bf16: s_max must be a multiple of 64");
@@ -318,10 +321,10 @@ extern "C" int dh_attn_prefill_bf16(const dh_bf16* q, const dh_bf16* k_cache, co
     hipStream_t s = (hipStream_t)stream;
     if (hs == 64)
         hipLaunchKernelGGL((attn_prefill_kernel<64>), grid, block, 0, s, q, k_cache, vT_cache, seq_slot, q_start, q_len,
-                           kv_pos0, y, n_head, n_groups, s_max, scale);
+                           kv_pos0, y, lse, n_head, n_groups, s_max, scale);
     else
         hipLaunchKernelGGL((attn_prefill_kernel<128>), grid, block, 0, s, q, k_cache, vT_cache, seq_slot, q_start, q_len,
-                           kv_pos0, y, n_head, n_groups, s_max, scale);
+                           kv_pos0, y, lse, n_head, n_groups, s_max, scale);
     DH_LAUNCH_CHECK();
     return 0;
 }

@@ -1,0 +1,293 @@
+// Backward of the causal GQA attention (training path, no KV cache: every sequence attends only to
+// itself).  Flash-style: P is recomputed from Q, K and the forward's log-sum-exp, nothing S x S is
+// stored.  Five MFMA products per (32-query, 32-key) tile pair, arranged so that every product either
+// contracts over the head dimension (operands = 16-byte runs of row-major rows) or takes a freshly
+// computed accumulator tile as its operand (cdna_hip_programming.md §3 "an accumulator tile as the
+// next MFMA's operand"); the other operand of those is then a column fragment, served from
+// token-contiguous transposed copies qT / doT / kT ([heads][hs][padded tokens], made by
+// transpose_pad_kernel; every sequence starts on a multiple of 32 there, so fragments are aligned).
+//
+//   dkdv kernel : grid (kv tile, group, seq), one wave per query head of the group
+//       S [q][key] = Q.K^T ; dP[q][key] = dO.V^T ; P = exp(S*scale - lse[q]) ; dS = P*(dP - D[q])
+//       dV^T[d][key] += dO^T[d][q] . P[q][key]      (A = doT fragment, B = P accumulator)
+//       dK^T[d][key] += Q^T [d][q] . dS[q][key]     (A = qT fragment,  B = dS accumulator)
+//       per-wave partials are summed over the group's heads through LDS
+//   dq kernel   : grid (q tile, head, seq), one wave
+//       S^T[key][q] = K.Q^T ; dP^T = V.dO^T ; dS^T = P^T*(dP^T - D[q])
+//       dQ^T[d][q] += K^T[d][key] . dS^T[key][q]    (A = kT fragment,  B = dS^T accumulator)
+#include "common.h"
+
+namespace {
+
+// src [n_tok, heads, hs] -> dst [heads, hs, n_pad]; token t of sequence i lands at pad_start[i] + (t - start[i])
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                            const int32_t* __restrict__ tok_seq,
+                                                            const int32_t* __restrict__ q_start,
+                                                            const int32_t* __restrict__ pad_start, int n_tok, int heads,
+                                                            int hs, int n_pad) {
+    __shared__ bf16_t tile[32][130];
+    const int t0 = blockIdx.x * 32, h = blockIdx.y;
+    for (int it = threadIdx.x; it < 32 * hs; it += 256) {
+        const int tl = it / hs, e = it % hs, t = t0 + tl;
+        tile[tl][e] = t < n_tok ? src[((size_t)t * heads + h) * hs + e] : (bf16_t)0;
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < 32 * hs; it += 256) {
+        const int tl = it & 31, e = it >> 5, t = t0 + tl;
+        if (t < n_tok) {
+            const int s = tok_seq[t];
+            dst[((size_t)h * hs + e) * n_pad + pad_start[s] + (t - q_start[s])] = tile[tl][e];
+        }
+    }
+}
+
+template <int HS>
+__global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+    const bf16_t* __restrict__ dout, const bf16_t* __restrict__ qT, const bf16_t* __restrict__ doT,
+    const float* __restrict__ lse, const float* __restrict__ dsum, const int32_t* __restrict__ q_start,
+    const int32_t* __restrict__ q_len, const int32_t* __restrict__ pad_start, bf16_t* __restrict__ dk,
+    bf16_t* __restrict__ dv, int n_head, int n_groups, int n_pad, float scale) {
+    constexpr int KS = HS / 16, DT = HS / 32;
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [waves][2][DT][16 regs][64 lanes]
+    const int seq = blockIdx.z, g = blockIdx.y, kt = blockIdx.x;
+    const int len = q_len[seq];
+    if (kt * 32 >= len) return;
+    const int qs = q_start[seq], ps = pad_start[seq];
+    const int q_per_kv = n_head / n_groups;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int head = g * q_per_kv + wave;
+    const int key0 = kt * 32;
+
+    // K and V row fragments of this key tile (B operands), kept for the whole block
+    bf16x8 kf[KS], vf[KS];
+    {
+        int key = key0 + lr;
+        key = key < len ? key : len - 1;
+        const bf16_t* kp = k + ((size_t)(qs + key) * n_groups + g) * HS + lh * 8;
+        const bf16_t* vp = v + ((size_t)(qs + key) * n_groups + g) * HS + lh * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            kf[ks] = *reinterpret_cast<const bf16x8*>(kp + ks * 16);
+            vf[ks] = *reinterpret_cast<const bf16x8*>(vp + ks * 16);
+        }
+    }
+    f32x16 dkT[DT], dvT[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dkT[dt][r] = 0.f; dvT[dt][r] = 0.f; }
+
+    const int n_qt = (len + 31) / 32;
+    const bf16_t* qTh = qT + (size_t)head * HS * n_pad + ps;
+    const bf16_t* doTh = doT + (size_t)head * HS * n_pad + ps;
+    for (int qt = kt; qt < n_qt; ++qt) {
+        const int q0 = qt * 32;
+        int qrow = q0 + lr;
+        qrow = qrow < len ? qrow : len - 1;
+        const bf16_t* qp = q + ((size_t)(qs + qrow) * n_head + head) * HS + lh * 8;
+        const bf16_t* dop = dout + ((size_t)(qs + qrow) * n_head + head) * HS + lh * 8;
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+            const bf16x8 dof = *reinterpret_cast<const bf16x8*>(dop + ks * 16);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], s, 0, 0, 0);       // rows q, cols key
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, vf[ks], dp, 0, 0, 0);
+        }
+        // P and dS in the accumulator layout: row (q) = (r&3) + 8*(r>>2) + 4*lh, col (key) = lr
+        const int key_abs = key0 + lr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qa = q0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const bool ok = qa < len && key_abs < len && key_abs <= qa;
+            const int qi = qa < len ? qa : len - 1;
+            const float l = lse[(size_t)(qs + qi) * n_head + head];
+            const float dd = dsum[(size_t)(qs + qi) * n_head + head];
+            const float p = ok ? __expf(s[r] * scale - l) : 0.f;
+            s[r] = p;
+            dp[r] = p * (dp[r] - dd);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            union { bf16x8 v; uint32_t u[4]; } pf, dsf;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                pf.u[j] = pack2bf(s[8 * s2 + 2 * j], s[8 * s2 + 2 * j + 1]);
+                dsf.u[j] = pack2bf(dp[8 * s2 + 2 * j], dp[8 * s2 + 2 * j + 1]);
+            }
+            const int qo = q0 + 16 * s2 + 4 * lh;        // tokens qo..qo+3 and qo+8..qo+11 (padded copy: in bounds)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const size_t row = (size_t)(dt * 32 + lr) * n_pad;
+                union { bf16x8 v; uint2 h[2]; } af, bfr;
+                af.h[0] = *reinterpret_cast<const uint2*>(doTh + row + qo);
+                af.h[1] = *reinterpret_cast<const uint2*>(doTh + row + qo + 8);
+                bfr.h[0] = *reinterpret_cast<const uint2*>(qTh + row + qo);
+                bfr.h[1] = *reinterpret_cast<const uint2*>(qTh + row + qo + 8);
+                dvT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.v, pf.v, dvT[dt], 0, 0, 0);    // [d][key]
+                dkT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr.v, dsf.v, dkT[dt], 0, 0, 0);
+            }
+        }
+    }
+    // ---- sum the heads of the group (LDS), then write dK (scaled) and dV: lane col = key, rows = d
+    float* mine = red + (size_t)wave * 2 * DT * 16 * 64;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            mine[((0 * DT + dt) * 16 + r) * 64 + lane] = dkT[dt][r];
+            mine[((1 * DT + dt) * 16 + r) * 64 + lane] = dvT[dt][r];
+        }
+    __syncthreads();
+    const int nw = q_per_kv;
+    for (int it = threadIdx.x; it < 2 * DT * 16 * 64; it += blockDim.x) {
+        float sum = 0.f;
+        for (int w = 0; w < nw; ++w) sum += red[(size_t)w * 2 * DT * 16 * 64 + it];
+        const int ln = it & 63, r = (it >> 6) & 15, dt = (it >> 10) % DT, which = it / (DT * 16 * 64);
+        const int key = key0 + (ln & 31);
+        const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+        if (key < len) {
+            bf16_t* dst = (which == 0 ? dk : dv) + ((size_t)(qs + key) * n_groups + g) * HS + d;
+            *dst = f2bf(which == 0 ? sum * scale : sum);
+        }
+    }
+}
+
+template <int HS>
+__global__ __launch_bounds__(64) void attn_bwd_dq_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+    const bf16_t* __restrict__ dout, const bf16_t* __restrict__ kT, const float* __restrict__ lse,
+    const float* __restrict__ dsum, const int32_t* __restrict__ q_start, const int32_t* __restrict__ q_len,
+    const int32_t* __restrict__ pad_start, bf16_t* __restrict__ dq, int n_head, int n_groups, int n_pad, float scale) {
+    constexpr int KS = HS / 16, DT = HS / 32;
+    const int seq = blockIdx.z, head = blockIdx.y, qt = blockIdx.x;
+    const int len = q_len[seq];
+    if (qt * 32 >= len) return;
+    const int qs = q_start[seq], ps = pad_start[seq];
+    const int g = head / (n_head / n_groups);
+    const int lane = threadIdx.x, lr = lane & 31, lh = lane >> 5;
+    const int q0 = qt * 32;
+    int qrow = q0 + lr;
+    const bool q_ok = qrow < len;
+    qrow = q_ok ? qrow : len - 1;
+    bf16x8 qf[KS], dof[KS];
+    {
+        const bf16_t* qp = q + ((size_t)(qs + qrow) * n_head + head) * HS + lh * 8;
+        const bf16_t* dop = dout + ((size_t)(qs + qrow) * n_head + head) * HS + lh * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+            dof[ks] = *reinterpret_cast<const bf16x8*>(dop + ks * 16);
+        }
+    }
+    const float l = lse[(size_t)(qs + qrow) * n_head + head];
+    const float dd = dsum[(size_t)(qs + qrow) * n_head + head];
+    const int q_abs = q0 + lr;
+    f32x16 dqT[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dqT[dt][r] = 0.f;
+    const bf16_t* kTg = kT + (size_t)g * HS * n_pad + ps;
+    for (int kt = 0; kt <= qt; ++kt) {
+        const int key0 = kt * 32;
+        int key = key0 + lr;
+        key = key < len ? key : len - 1;
+        const bf16_t* kp = k + ((size_t)(qs + key) * n_groups + g) * HS + lh * 8;
+        const bf16_t* vp = v + ((size_t)(qs + key) * n_groups + g) * HS + lh * 8;
+        f32x16 st, dpt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kp + ks * 16);
+            const bf16x8 vf = *reinterpret_cast<const bf16x8*>(vp + ks * 16);
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st, 0, 0, 0);        // rows key, cols q
+            dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dpt, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ka = key0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const bool ok = q_ok && ka < len && ka <= q_abs;
+            const float p = ok ? __expf(st[r] * scale - l) : 0.f;
+            st[r] = p * (dpt[r] - dd);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            union { bf16x8 v; uint32_t u[4]; } dsf;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dsf.u[j] = pack2bf(st[8 * s2 + 2 * j], st[8 * s2 + 2 * j + 1]);
+            const int ko = key0 + 16 * s2 + 4 * lh;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const size_t row = (size_t)(dt * 32 + lr) * n_pad;
+                union { bf16x8 v; uint2 h[2]; } af;
+                af.h[0] = *reinterpret_cast<const uint2*>(kTg + row + ko);
+                af.h[1] = *reinterpret_cast<const uint2*>(kTg + row + ko + 8);
+                dqT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.v, dsf.v, dqT[dt], 0, 0, 0);   // [d][q]
+            }
+        }
+    }
+    if (q_ok) {
+        bf16_t* dst = dq + ((size_t)(qs + q0 + lr) * n_head + head) * HS;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int d = dt * 32 + 8 * rg + 4 * lh;
+                uint2 pk = make_uint2(pack2bf(dqT[dt][rg * 4 + 0] * scale, dqT[dt][rg * 4 + 1] * scale),
+                                      pack2bf(dqT[dt][rg * 4 + 2] * scale, dqT[dt][rg * 4 + 3] * scale));
+                *reinterpret_cast<uint2*>(dst + d) = pk;
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int dh_transpose_pad_bf16(const dh_bf16* src, dh_bf16* dst, const int32_t* tok_seq, const int32_t* q_start,
+                                     const int32_t* pad_start, int n_tok, int heads, int hs, int n_pad, void* stream) {
+    DH_CHECK(src && dst && tok_seq && q_start && pad_start && hs <= 128 && n_pad % 32 == 0, "dh_transpose_pad_bf16: bad argument");
+    if (n_tok <= 0) return 0;
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3(cdiv(n_tok, 32), heads), dim3(256), 0, (hipStream_t)stream, src, dst, tok_seq,
+                       q_start, pad_start, n_tok, heads, hs, n_pad);
+    DH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dh_attn_bwd_bf16(const dh_bf16* q, const dh_bf16* k, const dh_bf16* v, const dh_bf16* dout,
+                                const dh_bf16* qT, const dh_bf16* doT, const dh_bf16* kT, const float* lse,
+                                const float* dsum, const int32_t* q_start, const int32_t* q_len, const int32_t* pad_start,
+                                dh_bf16* dq, dh_bf16* dk, dh_bf16* dv, int n_seq, int max_q_len, int n_head, int n_groups,
+                                int hs, int n_pad, void* stream) {
+    DH_CHECK(q && k && v && dout && qT && doT && kT && lse && dsum && dq && dk && dv, "dh_attn_bwd_bf16: null argument");
+    DH_CHECK(hs == 64 || hs == 128, "dh_attn_bwd_bf16: head_size %d unsupported", hs);
+    DH_CHECK(n_groups > 0 && n_head % n_groups == 0 && n_head / n_groups <= 8, "dh_attn_bwd_bf16: at most 8 query heads per group");
+    DH_CHECK(n_pad % 32 == 0, "dh_attn_bwd_bf16: n_pad must be a multiple of 32");
+    if (n_seq <= 0 || max_q_len <= 0) return 0;
+    const float scale = 1.0f / sqrtf((float)hs);
+    const int nt = cdiv(max_q_len, 32), qpk = n_head / n_groups;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = (size_t)qpk * 2 * (hs / 32) * 16 * 64 * sizeof(float);
+    if (hs == 64) {
+        static bool attr = false;
+        if (!attr) { DH_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64>), dim3(nt, n_groups, n_seq), dim3(64 * qpk), lds, s, q, k, v, dout, qT, doT,
+                           lse, dsum, q_start, q_len, pad_start, dk, dv, n_head, n_groups, n_pad, scale);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), dim3(nt, n_head, n_seq), dim3(64), 0, s, q, k, v, dout, kT, lse, dsum,
+                           q_start, q_len, pad_start, dq, n_head, n_groups, n_pad, scale);
+    } else {
+        DH_CHECK(lds <= 160 * 1024, "dh_attn_bwd_bf16: too many heads per group for head_size 128");
+        static bool attr = false;
+        if (!attr) { DH_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128>), dim3(nt, n_groups, n_seq), dim3(64 * qpk), lds, s, q, k, v, dout, qT, doT,
+                           lse, dsum, q_start, q_len, pad_start, dk, dv, n_head, n_groups, n_pad, scale);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<128>), dim3(nt, n_head, n_seq), dim3(64), 0, s, q, k, v, dout, kT, lse, dsum,
+                           q_start, q_len, pad_start, dq, n_head, n_groups, n_pad, scale);
+    }
+    DH_LAUNCH_CHECK();
+    return 0;
+}

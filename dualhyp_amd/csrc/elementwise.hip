@@ -122,7 +122,8 @@ template <int HS>
 __global__ __launch_bounds__(256) void qkv_rope_cache_kernel(
     const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ cos, const bf16_t* __restrict__ sin,
     const int32_t* __restrict__ tok_slot, const int32_t* __restrict__ tok_pos, bf16_t* __restrict__ q_out,
-    bf16_t* __restrict__ k_cache, bf16_t* __restrict__ vT_cache, int n_tok, int n_head, int n_groups, int s_max) {
+    bf16_t* __restrict__ k_cache, bf16_t* __restrict__ vT_cache, bf16_t* __restrict__ k_out, bf16_t* __restrict__ v_out,
+    int n_tok, int n_head, int n_groups, int s_max) {
     constexpr int HALF = HS / 2;
     constexpr int CPH = HALF / 8;              // 16-B chunk pairs per head
     const int g = blockIdx.y;
@@ -166,6 +167,11 @@ __global__ __launch_bounds__(256) void qkv_rope_cache_kernel(
             bf16_t* kb = k_cache + ((size_t)tok_slot[t] * n_groups + g) * s_max * HS;
             *reinterpret_cast<uint4*>(kb + kfrag_off<HS>(pos, c * 8)) = o1;
             *reinterpret_cast<uint4*>(kb + kfrag_off<HS>(pos, HALF + c * 8)) = o2;
+            if (k_out != nullptr) {   // plain [n_tok, g, hs] copy for the training backward
+                bf16_t* ko = k_out + ((size_t)t * n_groups + g) * HS;
+                *reinterpret_cast<uint4*>(ko + c * 8) = o1;
+                *reinterpret_cast<uint4*>(ko + HALF + c * 8) = o2;
+            }
         }
     }
 
@@ -176,6 +182,7 @@ __global__ __launch_bounds__(256) void qkv_rope_cache_kernel(
         uint4 u = make_uint4(0, 0, 0, 0);
         if (t < n_tok) u = *reinterpret_cast<const uint4*>(qkv + (size_t)t * row_elems + grp_off + (q_per_kv + 1) * HS + c * 8);
         *reinterpret_cast<uint4*>(&vt[tl][c * 8]) = u;
+        if (v_out != nullptr && t < n_tok) *reinterpret_cast<uint4*>(v_out + ((size_t)t * n_groups + g) * HS + c * 8) = u;
     }
     __syncthreads();
     for (int it = threadIdx.x; it < 64 * HS; it += 256) {
@@ -189,8 +196,8 @@ __global__ __launch_bounds__(256) void qkv_rope_cache_kernel(
 
 extern "C" int dh_qkv_rope_cache_bf16(const dh_bf16* qkv, const dh_bf16* cos, const dh_bf16* sin,
                                       const int32_t* tok_slot, const int32_t* tok_pos, dh_bf16* q_out,
-                                      dh_bf16* k_cache, dh_bf16* vT_cache, int n_tok, int n_head, int n_groups,
-                                      int hs, int s_max, void* stream) {
+                                      dh_bf16* k_cache, dh_bf16* vT_cache, dh_bf16* k_out, dh_bf16* v_out, int n_tok,
+                                      int n_head, int n_groups, int hs, int s_max, void* stream) {
     DH_CHECK(n_tok >= 0 && n_groups > 0 && n_head % n_groups == 0, "dh_qkv_rope_cache_bf16: bad head counts");
     DH_CHECK(hs == 64 || hs == 128, "dh_qkv_rope_cache_bf16: head_size %d unsupported (64 or 128)", hs);
     if (n_tok == 0) return 0;
@@ -198,10 +205,10 @@ extern "C" int dh_qkv_rope_cache_bf16(const dh_bf16* qkv, const dh_bf16* cos, co
     hipStream_t s = (hipStream_t)stream;
     if (hs == 64)
         hipLaunchKernelGGL((qkv_rope_cache_kernel<64>), grid, block, 0, s, qkv, cos, sin, tok_slot, tok_pos, q_out,
-                           k_cache, vT_cache, n_tok, n_head, n_groups, s_max);
+                           k_cache, vT_cache, k_out, v_out, n_tok, n_head, n_groups, s_max);
     else
         hipLaunchKernelGGL((qkv_rope_cache_kernel<128>), grid, block, 0, s, qkv, cos, sin, tok_slot, tok_pos, q_out,
-                           k_cache, vT_cache, n_tok, n_head, n_groups, s_max);
+                           k_cache, vT_cache, k_out, v_out, n_tok, n_head, n_groups, s_max);
     DH_LAUNCH_CHECK();
     return 0;
 }

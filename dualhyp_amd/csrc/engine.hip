@@ -140,16 +140,16 @@ int run_layers(dh_engine* e, const int64_t* ids, int n_tok, int n_seq, int max_q
             if ((rc = linear(e, e->xn, W.attn_w, e->qkv, n_tok, e->qkv_dim, d, DH_EPI_PLAIN, nullptr, nullptr, 0, nullptr,
                              0, 0, nullptr, nullptr, nullptr, s, true))) return rc;
         }
-        if ((rc = dh_qkv_rope_cache_bf16(e->qkv, D.rope_cos, D.rope_sin, e->tok_slot, e->tok_pos, e->qrot, kc, vtc, n_tok,
-                                         H, G, hs, e->s_max, s))) return rc;
+        if ((rc = dh_qkv_rope_cache_bf16(e->qkv, D.rope_cos, D.rope_sin, e->tok_slot, e->tok_pos, e->qrot, kc, vtc, nullptr,
+                                         nullptr, n_tok, H, G, hs, e->s_max, s))) return rc;
         if (decode) {
             TimeScope t(e, 3, s);
             if ((rc = dh_attn_decode_bf16(e->qrot, kc, vtc, seq_slot, kv_pos0, e->att, e->dec_work, n_seq, H, G, hs,
                                           e->s_max, s))) return rc;
         } else {
             TimeScope t(e, 2, s);
-            if ((rc = dh_attn_prefill_bf16(e->qrot, kc, vtc, seq_slot, q_start, q_len, kv_pos0, e->att, n_seq, max_q_len,
-                                           H, G, hs, e->s_max, s))) return rc;
+            if ((rc = dh_attn_prefill_bf16(e->qrot, kc, vtc, seq_slot, q_start, q_len, kv_pos0, e->att, nullptr, n_seq,
+                                           max_q_len, H, G, hs, e->s_max, s))) return rc;
         }
         if (W.proj_lora_a) {
             if ((rc = linear(e, e->att, W.proj_lora_a, e->xa, n_tok, 16, d, DH_EPI_PLAIN, nullptr, nullptr, 0, nullptr, 0, 0,

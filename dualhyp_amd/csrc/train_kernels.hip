@@ -1,0 +1,213 @@
+// Backward-pass kernels of the LoRA fine-tune (finetune/ger.py:278-292): everything except the dX
+// GEMMs (those reuse gemm.hip / gemm256.hip on transposed copies of the frozen weights) and the
+// attention backward (attention_bwd.hip).  Activations and activation-gradients are bf16, sums are
+// fp32, LoRA gradients are accumulated in fp32 buffers.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------- SwiGLU backward
+// act = bf16(silu(g)) * u  (ger/model.py:313-315)  ->  dg = dact * u * silu'(g), du = dact * silu(g)
+// out: dgu [rows, 2*I] = [dg | du]  (feeds ONE dX GEMM against [fc_1 ; fc_2] stacked along K)
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ dact, const bf16_t* __restrict__ g,
+                                                         const bf16_t* __restrict__ u, bf16_t* __restrict__ dgu,
+                                                         size_t rows, int I) {
+    const size_t n8 = rows * (size_t)(I / 8);
+    for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < n8; c += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = c / (I / 8);
+        const int col = (int)(c % (I / 8)) * 8;
+        const uint4 da = *reinterpret_cast<const uint4*>(dact + row * I + col);
+        const uint4 gv = *reinterpret_cast<const uint4*>(g + row * I + col);
+        const uint4 uv = *reinterpret_cast<const uint4*>(u + row * I + col);
+        const bf16_t *dp = (const bf16_t*)&da, *gp = (const bf16_t*)&gv, *up = (const bf16_t*)&uv;
+        uint4 og, ou;
+        bf16_t *ogp = (bf16_t*)&og, *oup = (bf16_t*)&ou;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float gg = bf2f(gp[e]), d = bf2f(dp[e]);
+            const float sig = 1.0f / (1.0f + expf(-gg));
+            const float s = rbf(gg * sig);                      // silu(g) as the forward rounded it
+            ogp[e] = f2bf(d * bf2f(up[e]) * (sig * (1.0f + gg * (1.0f - sig))));
+            oup[e] = f2bf(d * s);
+        }
+        *reinterpret_cast<uint4*>(dgu + row * 2 * I + col) = og;
+        *reinterpret_cast<uint4*>(dgu + row * 2 * I + I + col) = ou;
+    }
+}
+
+// ---------------------------------------------------------------------------------- RMSNorm backward
+// y = w * x * r, r = rsqrt(mean(x^2)+eps):  dx = r * (w*dy) - x * r^3 * mean(x * w*dy)   (+ dres)
+// one wave per row, row in registers.  dx_out = bf16(dx + dres) when dres != null.
+template <int MAXC>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                          const bf16_t* __restrict__ w, const bf16_t* __restrict__ dres,
+                                                          bf16_t* __restrict__ dx, int rows, int d, float eps) {
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int nchunk = d >> 3;
+    float xv[MAXC][8], gv[MAXC][8];
+    float ss = 0.f, sg = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nchunk) {
+            const uint4 xu = reinterpret_cast<const uint4*>(x + (size_t)row * d)[c];
+            const uint4 du = reinterpret_cast<const uint4*>(dy + (size_t)row * d)[c];
+            const uint4 wu = reinterpret_cast<const uint4*>(w)[c];
+            const bf16_t *xp = (const bf16_t*)&xu, *dp = (const bf16_t*)&du, *wp = (const bf16_t*)&wu;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                xv[i][e] = bf2f(xp[e]);
+                gv[i][e] = bf2f(dp[e]) * bf2f(wp[e]);
+                ss += xv[i][e] * xv[i][e];
+                sg += xv[i][e] * gv[i][e];
+            }
+        }
+    }
+    ss = wave_sum(ss);
+    sg = wave_sum(sg);
+    const float r = 1.0f / sqrtf(ss / (float)d + eps);
+    const float k = r * r * r * sg / (float)d;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nchunk) {
+            uint4 o;
+            bf16_t* op = (bf16_t*)&o;
+            uint4 ru = make_uint4(0, 0, 0, 0);
+            if (dres) ru = reinterpret_cast<const uint4*>(dres + (size_t)row * d)[c];
+            const bf16_t* rp = (const bf16_t*)&ru;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) op[e] = f2bf(r * gv[i][e] - k * xv[i][e] + (dres ? bf2f(rp[e]) : 0.f));
+            reinterpret_cast<uint4*>(dx + (size_t)row * d)[c] = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------- rope backward
+// forward: o1 = x1*c1 - x2*s1 ; o2 = x2*c2 + x1*s2  (ger/model.py:349-355)
+// backward: dx1 = do1*c1 + do2*s2 ; dx2 = do2*c2 - do1*s1.   v passes through.  Gathers the three
+// gradient tensors back into the group-interleaved fused-qkv layout.
+template <int HS>
+__global__ __launch_bounds__(256) void qkv_rope_bwd_kernel(const bf16_t* __restrict__ dq, const bf16_t* __restrict__ dk,
+                                                           const bf16_t* __restrict__ dv, const bf16_t* __restrict__ cos,
+                                                           const bf16_t* __restrict__ sin, const int32_t* __restrict__ tok_pos,
+                                                           bf16_t* __restrict__ dqkv, int n_tok, int n_head, int n_groups) {
+    constexpr int HALF = HS / 2;
+    const int q_per_kv = n_head / n_groups;
+    const int heads = q_per_kv + 2;
+    const int row_elems = n_groups * heads * HS;
+    const size_t total = (size_t)n_tok * n_groups * heads * HALF;
+    for (size_t it = blockIdx.x * (size_t)blockDim.x + threadIdx.x; it < total; it += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(it % HALF);
+        const int j = (int)((it / HALF) % heads);
+        const int g = (int)((it / ((size_t)HALF * heads)) % n_groups);
+        const int t = (int)(it / ((size_t)HALF * heads * n_groups));
+        bf16_t* dst = dqkv + (size_t)t * row_elems + (g * heads + j) * HS;
+        if (j == q_per_kv + 1) {                       // v: straight copy
+            const bf16_t* s = dv + ((size_t)t * n_groups + g) * HS;
+            dst[i] = s[i];
+            dst[HALF + i] = s[HALF + i];
+            continue;
+        }
+        const bf16_t* s = j < q_per_kv ? dq + ((size_t)t * n_head + g * q_per_kv + j) * HS : dk + ((size_t)t * n_groups + g) * HS;
+        const int pos = tok_pos[t];
+        const float c1 = bf2f(cos[(size_t)pos * HS + i]), c2 = bf2f(cos[(size_t)pos * HS + HALF + i]);
+        const float s1 = bf2f(sin[(size_t)pos * HS + i]), s2 = bf2f(sin[(size_t)pos * HS + HALF + i]);
+        const float d1 = bf2f(s[i]), d2 = bf2f(s[HALF + i]);
+        dst[i] = f2bf(d1 * c1 + d2 * s2);
+        dst[HALF + i] = f2bf(d2 * c2 - d1 * s1);
+    }
+}
+
+// ---------------------------------------------------------------------------------- LoRA gradients
+// out[m][n] (+)= scale * sum_t a[t][m] * b[t][n]      (contraction over tokens)
+//   a: [T, lda] bf16 (columns m0..), b: [T, ldb] bf16.  One 16 x 16 output tile per block of 256 threads:
+//   thread (m, n) strides over t in 4 phases ... kept simple: T <= a few thousand, M*N <= 2560*16.
+__global__ __launch_bounds__(256) void tn_accum_kernel(const bf16_t* __restrict__ a, int lda, const bf16_t* __restrict__ b,
+                                                       int ldb, float* __restrict__ out, int ldo, int T, int M, int N,
+                                                       float scale, int accumulate) {
+    __shared__ float red[4][16][17];
+    const int m0 = blockIdx.x * 16, n0 = blockIdx.y * 16;
+    const int tid = threadIdx.x, lm = tid & 15, ln = (tid >> 4) & 15 & 15;
+    // 256 threads = 16 (m) x 16 (n); every thread walks all tokens (coalescing across lm for a, ln for b)
+    const int m = m0 + lm, n = n0 + (tid >> 4);
+    (void)ln; (void)red;
+    float acc = 0.f;
+    if (m < M && n < N)
+        for (int t = 0; t < T; ++t) acc = fmaf(bf2f(a[(size_t)t * lda + m]), bf2f(b[(size_t)t * ldb + n]), acc);
+    if (m < M && n < N) {
+        float* o = out + (size_t)m * ldo + n;
+        *o = (accumulate ? *o : 0.f) + scale * acc;
+    }
+}
+
+// D[t][h] = sum_d dO[t][h][d] * O[t][h][d]   (softmax backward row term)
+__global__ __launch_bounds__(256) void rowdot_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                                     float* __restrict__ out, size_t rows, int hs) {
+    const size_t row = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 4;   // 16 lanes per row
+    const int l = threadIdx.x & 15;
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int e = l; e < hs; e += 16) s += bf2f(a[row * hs + e]) * bf2f(b[row * hs + e]);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 16);
+    if (l == 0) out[row] = s;
+}
+
+}  // namespace
+
+extern "C" int dh_swiglu_bwd_bf16(const dh_bf16* dact, const dh_bf16* g, const dh_bf16* u, dh_bf16* dgu, int rows, int I,
+                                  void* stream) {
+    DH_CHECK(dact && g && u && dgu && rows >= 0 && I % 8 == 0, "dh_swiglu_bwd_bf16: bad argument");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, dact, g, u, dgu, (size_t)rows, I);
+    DH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dh_rmsnorm_bwd_bf16(const dh_bf16* dy, const dh_bf16* x, const dh_bf16* w, const dh_bf16* dres, dh_bf16* dx,
+                                   int rows, int d, float eps, void* stream) {
+    DH_CHECK(dy && x && w && dx && d % 8 == 0 && d <= 8192, "dh_rmsnorm_bwd_bf16: bad argument (d=%d)", d);
+    if (rows <= 0) return 0;
+    dim3 grid(cdiv(rows, 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(MAXC) hipLaunchKernelGGL((rmsnorm_bwd_kernel<MAXC>), grid, block, 0, s, dy, x, w, dres, dx, rows, d, eps)
+    if (d <= 512) { LAUNCH(1); } else if (d <= 2048) { LAUNCH(4); } else if (d <= 4096) { LAUNCH(8); } else { LAUNCH(16); }
+#undef LAUNCH
+    DH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dh_qkv_rope_bwd_bf16(const dh_bf16* dq, const dh_bf16* dk, const dh_bf16* dv, const dh_bf16* cos,
+                                    const dh_bf16* sin, const int32_t* tok_pos, dh_bf16* dqkv, int n_tok, int n_head,
+                                    int n_groups, int hs, void* stream) {
+    DH_CHECK(dq && dk && dv && cos && sin && tok_pos && dqkv, "dh_qkv_rope_bwd_bf16: null argument");
+    DH_CHECK(hs == 64 || hs == 128, "dh_qkv_rope_bwd_bf16: head_size %d unsupported", hs);
+    if (n_tok <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (hs == 64)
+        hipLaunchKernelGGL((qkv_rope_bwd_kernel<64>), dim3(1024), dim3(256), 0, s, dq, dk, dv, cos, sin, tok_pos, dqkv, n_tok, n_head, n_groups);
+    else
+        hipLaunchKernelGGL((qkv_rope_bwd_kernel<128>), dim3(1024), dim3(256), 0, s, dq, dk, dv, cos, sin, tok_pos, dqkv, n_tok, n_head, n_groups);
+    DH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dh_tn_accum_f32(const dh_bf16* a, int lda, const dh_bf16* b, int ldb, float* out, int ldo, int T, int M,
+                               int N, float scale, int accumulate, void* stream) {
+    DH_CHECK(a && b && out && T >= 0 && M > 0 && N > 0, "dh_tn_accum_f32: bad argument");
+    hipLaunchKernelGGL(tn_accum_kernel, dim3(cdiv(M, 16), cdiv(N, 16)), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, out,
+                       ldo, T, M, N, scale, accumulate);
+    DH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dh_rowdot_f32(const dh_bf16* a, const dh_bf16* b, float* out, int64_t rows, int hs, void* stream) {
+    DH_CHECK(a && b && out && hs > 0, "dh_rowdot_f32: bad argument");
+    if (rows <= 0) return 0;
+    hipLaunchKernelGGL(rowdot_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, (hipStream_t)stream, a, b, out,
+                       (size_t)rows, hs);
+    DH_LAUNCH_CHECK();
+    return 0;
+}

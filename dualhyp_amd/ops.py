@@ -87,27 +87,29 @@ def linear(x: torch.Tensor, w: torch.Tensor, *, epilogue: int = EPI_PLAIN, w2: O
 
 def qkv_rope_cache(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, tok_slot: torch.Tensor,
                    tok_pos: torch.Tensor, k_cache: torch.Tensor, vT_cache: torch.Tensor, n_head: int,
-                   n_groups: int) -> torch.Tensor:
-    """-> rotated q [n_tok, n_head, hs]; appends k / v^T into the caches in place."""
+                   n_groups: int, k_out: Optional[torch.Tensor] = None, v_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """-> rotated q [n_tok, n_head, hs]; appends k / v^T into the caches in place (and, for training,
+    plain copies into k_out / v_out [n_tok, n_groups, hs])."""
     qkv = _dev(qkv, name="qkv")
     hs = k_cache.size(-1)
     s_max = k_cache.size(-2)
     n_tok = qkv.numel() // ((n_head + 2 * n_groups) * hs)
     q = torch.empty((n_tok, n_head, hs), dtype=torch.bfloat16, device=qkv.device)
     check(_lib.load().dh_qkv_rope_cache_bf16(_p(qkv), _p(_dev(cos)), _p(_dev(sin)), _p(_dev(tok_slot, torch.int32)),
-                                             _p(_dev(tok_pos, torch.int32)), _p(q), _p(k_cache), _p(vT_cache), n_tok,
-                                             n_head, n_groups, hs, s_max, _stream()))
+                                             _p(_dev(tok_pos, torch.int32)), _p(q), _p(k_cache), _p(vT_cache), _p(k_out),
+                                             _p(v_out), n_tok, n_head, n_groups, hs, s_max, _stream()))
     return q
 
 
 def attn_prefill(q: torch.Tensor, k_cache: torch.Tensor, vT_cache: torch.Tensor, seq_slot: torch.Tensor,
-                 q_start: torch.Tensor, q_len: torch.Tensor, kv_pos0: torch.Tensor, max_q_len: int) -> torch.Tensor:
+                 q_start: torch.Tensor, q_len: torch.Tensor, kv_pos0: torch.Tensor, max_q_len: int,
+                 lse: Optional[torch.Tensor] = None) -> torch.Tensor:
     n_tok, n_head, hs = q.shape
     n_groups, s_max = k_cache.size(1), k_cache.size(2)
     y = torch.empty((n_tok, n_head * hs), dtype=torch.bfloat16, device=q.device)
     i32 = torch.int32
     check(_lib.load().dh_attn_prefill_bf16(_p(_dev(q)), _p(k_cache), _p(vT_cache), _p(_dev(seq_slot, i32)),
-                                           _p(_dev(q_start, i32)), _p(_dev(q_len, i32)), _p(_dev(kv_pos0, i32)), _p(y),
+                                           _p(_dev(q_start, i32)), _p(_dev(q_len, i32)), _p(_dev(kv_pos0, i32)), _p(y), _p(lse),
                                            seq_slot.numel(), int(max_q_len), n_head, n_groups, hs, s_max, _stream()))
     return y
 
@@ -190,3 +192,66 @@ def vcache_to_plain(vt: torch.Tensor) -> torch.Tensor:
     B, G, hs, S = vt.shape
     v = vt.reshape(B, G, S // 32, hs // 32, 2, 2, 32, 2, 4)      # tile, dt, s2, lh, lr, jh, jl
     return v.permute(0, 1, 3, 6, 2, 4, 7, 5, 8).reshape(B, G, hs, S)
+
+
+# ------------------------------------------------------------------------------------------ training backward
+def swiglu_bwd(dact: torch.Tensor, g: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
+    rows, I = g.shape
+    out = torch.empty((rows, 2 * I), dtype=torch.bfloat16, device=g.device)
+    check(_lib.load().dh_swiglu_bwd_bf16(_p(_dev(dact)), _p(_dev(g)), _p(_dev(u)), _p(out), rows, I, _stream()))
+    return out
+
+
+def rmsnorm_bwd(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, eps: float, dres: Optional[torch.Tensor] = None) -> torch.Tensor:
+    d = x.size(-1)
+    dx = torch.empty_like(x)
+    check(_lib.load().dh_rmsnorm_bwd_bf16(_p(_dev(dy)), _p(_dev(x)), _p(_dev(w)), _p(dres), _p(dx), x.numel() // d, d,
+                                          float(eps), _stream()))
+    return dx
+
+
+def qkv_rope_bwd(dq: torch.Tensor, dk: torch.Tensor, dv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
+                 tok_pos: torch.Tensor) -> torch.Tensor:
+    n_tok, n_head, hs = dq.shape
+    n_groups = dk.size(1)
+    out = torch.empty((n_tok, (n_head + 2 * n_groups) * hs), dtype=torch.bfloat16, device=dq.device)
+    check(_lib.load().dh_qkv_rope_bwd_bf16(_p(_dev(dq)), _p(_dev(dk)), _p(_dev(dv)), _p(_dev(cos)), _p(_dev(sin)),
+                                           _p(_dev(tok_pos, torch.int32)), _p(out), n_tok, n_head, n_groups, hs, _stream()))
+    return out
+
+
+def tn_accum(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, scale: float = 1.0, accumulate: bool = True) -> None:
+    """out[M,N] (+)= scale * a[T,M].T @ b[T,N]; a/b may be column slices of wider row-major matrices."""
+    assert a.stride(1) == 1 and b.stride(1) == 1 and out.dtype == torch.float32 and out.stride(1) == 1
+    T, M = a.shape
+    N = b.size(1)
+    check(_lib.load().dh_tn_accum_f32(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0),
+                                      T, M, N, float(scale), int(accumulate), _stream()))
+
+
+def attn_bwd(q, k, v, out, dout, lse, q_start, q_len, max_q_len: int):
+    """-> (dq, dk, dv) of the causal GQA attention of a packed batch (sequences attend to themselves)."""
+    n_tok, H, hs = q.shape
+    G = k.size(1)
+    lib = _lib.load()
+    dev = q.device
+    lens = q_len.tolist()
+    pads = [-(-n // 32) * 32 for n in lens]
+    pad_start = torch.tensor([sum(pads[:i]) for i in range(len(pads))], dtype=torch.int32, device=dev)
+    n_pad = sum(pads)
+    tok_seq = torch.repeat_interleave(torch.arange(len(lens), dtype=torch.int32, device=dev), q_len.to(torch.int64))
+    dout = _dev(dout.reshape(n_tok, H, hs))
+    dsum = torch.empty((n_tok, H), dtype=torch.float32, device=dev)
+    check(lib.dh_rowdot_f32(_p(dout), _p(_dev(out.reshape(n_tok, H, hs))), _p(dsum), n_tok * H, hs, _stream()))
+
+    def tpad(src, heads):
+        dst = torch.zeros((heads, hs, n_pad), dtype=torch.bfloat16, device=dev)
+        check(lib.dh_transpose_pad_bf16(_p(_dev(src)), _p(dst), _p(tok_seq), _p(q_start), _p(pad_start), n_tok, heads, hs,
+                                        n_pad, _stream()))
+        return dst
+    qT, doT, kT = tpad(q, H), tpad(dout, H), tpad(k, G)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    check(lib.dh_attn_bwd_bf16(_p(q), _p(k), _p(v), _p(dout), _p(qT), _p(doT), _p(kT), _p(lse), _p(dsum), _p(q_start),
+                               _p(q_len), _p(pad_start), _p(dq), _p(dk), _p(dv), len(lens), int(max_q_len), H, G, hs,
+                               n_pad, _stream()))
+    return dq, dk, dv

@@ -61,11 +61,13 @@ int dh_rmsnorm_bf16(const dh_bf16* x, const dh_bf16* resid, const dh_bf16* w, dh
  *   q_out  [n_tok, n_head, hs]            rotated queries
  *   k_cache [n_slots, n_groups, s_max, hs]   (compact GQA cache; the reference's 8x expansion
  *   vT_cache[n_slots, n_groups, hs, s_max]    ger/model.py:225-227 is not materialised)
- * tok_slot[t], tok_pos[t]: cache slot (sequence) and position of token t. */
+ * tok_slot[t], tok_pos[t]: cache slot (sequence) and position of token t.
+ * k_out / v_out (nullable): plain [n_tok, n_groups, hs] copies of the rotated k and of v, kept by
+ * the training forward for the attention backward. */
 int dh_qkv_rope_cache_bf16(const dh_bf16* qkv, const dh_bf16* cos, const dh_bf16* sin,
                            const int32_t* tok_slot, const int32_t* tok_pos, dh_bf16* q_out,
-                           dh_bf16* k_cache, dh_bf16* vT_cache, int n_tok, int n_head,
-                           int n_groups, int hs, int s_max, void* stream);
+                           dh_bf16* k_cache, dh_bf16* vT_cache, dh_bf16* k_out, dh_bf16* v_out,
+                           int n_tok, int n_head, int n_groups, int hs, int s_max, void* stream);
 
 /* ------------------------------------------------------------------ GEMMs (MFMA) */
 
@@ -114,10 +116,11 @@ int dh_finish_norm_bf16(const float* h32, int n_part, int rows, int d, int n_ext
 /* Causal attention of a packed batch against the KV cache — ger/model.py:261,270-290 with the
  * boolean mask of ger/lora.py:530-531.  Sequence i owns q rows [q_start[i], q_start[i]+q_len[i])
  * of q [n_tok, n_head, hs]; row j of it sits at position kv_pos0[i]+j and attends cache
- * positions 0..kv_pos0[i]+j of slot seq_slot[i].  y: [n_tok, n_head*hs].  scale = 1/sqrt(hs). */
+ * positions 0..kv_pos0[i]+j of slot seq_slot[i].  y: [n_tok, n_head*hs].  scale = 1/sqrt(hs).
+ * lse (nullable): [n_tok, n_head] fp32 log-sum-exp of the scaled scores, kept for the backward. */
 int dh_attn_prefill_bf16(const dh_bf16* q, const dh_bf16* k_cache, const dh_bf16* vT_cache,
                          const int32_t* seq_slot, const int32_t* q_start, const int32_t* q_len,
-                         const int32_t* kv_pos0, dh_bf16* y, int n_seq, int max_q_len,
+                         const int32_t* kv_pos0, dh_bf16* y, float* lse, int n_seq, int max_q_len,
                          int n_head, int n_groups, int hs, int s_max, void* stream);
 
 /* One query token per sequence (decode step): q [n_seq, n_head, hs]; sequence i attends cache
@@ -138,6 +141,39 @@ int dh_attn_decode_fused_bf16(const float* qkv32, int n_part, int n_seq, int qkv
                               const int32_t* kv_len, dh_bf16* k_cache, dh_bf16* vT_cache,
                               dh_bf16* y, int n_head, int n_groups, int hs, int s_max,
                               void* stream);
+
+/* ------------------------------------------------------------------ LoRA fine-tune backward
+ * finetune/ger.py:278-285 `fabric.backward(loss / accum)` for the frozen-base / LoRA-only case: the dX
+ * GEMMs reuse dh_linear_bf16 on transposed copies of the frozen weights; these are the rest. */
+
+/* dgu[rows, 2I] = [dact*u*silu'(g) | dact*silu(g)]   (backward of ger/model.py:315) */
+int dh_swiglu_bwd_bf16(const dh_bf16* dact, const dh_bf16* g, const dh_bf16* u, dh_bf16* dgu, int rows,
+                       int I, void* stream);
+/* dx = d(RMSNorm)/dx . dy (+ dres)   (backward of ger/rmsnorm.py:17-21; fp32 internally) */
+int dh_rmsnorm_bwd_bf16(const dh_bf16* dy, const dh_bf16* x, const dh_bf16* w, const dh_bf16* dres,
+                        dh_bf16* dx, int rows, int d, float eps, void* stream);
+/* conjugate rotation of dq / dk, pass-through of dv, scattered back into the fused-qkv layout
+ * (backward of ger/model.py:216-246; cf. ger/fused_rotary_embedding.py:49-90) */
+int dh_qkv_rope_bwd_bf16(const dh_bf16* dq, const dh_bf16* dk, const dh_bf16* dv, const dh_bf16* cos,
+                         const dh_bf16* sin, const int32_t* tok_pos, dh_bf16* dqkv, int n_tok,
+                         int n_head, int n_groups, int hs, void* stream);
+/* out[M,N] (+)= scale * a[T,M]^T . b[T,N]   (LoRA dA / dB: contraction over tokens), fp32 out */
+int dh_tn_accum_f32(const dh_bf16* a, int lda, const dh_bf16* b, int ldb, float* out, int ldo, int T,
+                    int M, int N, float scale, int accumulate, void* stream);
+/* out[row] = sum_d a[row,d]*b[row,d]   (softmax-backward row term D = rowsum(dO*O)) */
+int dh_rowdot_f32(const dh_bf16* a, const dh_bf16* b, float* out, int64_t rows, int hs, void* stream);
+/* src [n_tok, heads, hs] -> dst [heads, hs, n_pad], sequence i placed at pad_start[i] (multiple of 32) */
+int dh_transpose_pad_bf16(const dh_bf16* src, dh_bf16* dst, const int32_t* tok_seq,
+                          const int32_t* q_start, const int32_t* pad_start, int n_tok, int heads,
+                          int hs, int n_pad, void* stream);
+/* Causal GQA attention backward (no KV cache; ger/model.py:287-289 under autograd): dq [n_tok,H,hs],
+ * dk / dv [n_tok,G,hs] from q, k, v (rotated, plain), dout, lse (dh_attn_prefill_bf16) and
+ * dsum = rowsum(dout*out); qT / doT / kT from dh_transpose_pad_bf16. */
+int dh_attn_bwd_bf16(const dh_bf16* q, const dh_bf16* k, const dh_bf16* v, const dh_bf16* dout,
+                     const dh_bf16* qT, const dh_bf16* doT, const dh_bf16* kT, const float* lse,
+                     const float* dsum, const int32_t* q_start, const int32_t* q_len,
+                     const int32_t* pad_start, dh_bf16* dq, dh_bf16* dk, dh_bf16* dv, int n_seq,
+                     int max_q_len, int n_head, int n_groups, int hs, int n_pad, void* stream);
 
 /* ------------------------------------------------------------------ token sampling */
 

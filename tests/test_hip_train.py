@@ -1,0 +1,97 @@
+"""GPU tests of the LoRA fine-tune backward kernels against torch autograd (fp32 on the CPU) of the
+oracle's forward ops.  Gradients are bf16 tensors: tolerance 1.5% of the reference's max magnitude
+(+ 1 bf16 ulp), the level at which two bf16 backward passes agree."""
+import math
+
+import pytest
+import torch
+
+from dualhyp_amd.synth import uniform, stream_id
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def U(shape, bound, name, seed=21):
+    return uniform(shape, bound, stream_id(seed, name))
+
+
+def close(got, want, what, rel=1.5e-2):
+    got, want = got.float().cpu(), want.float()
+    tol = rel * want.abs().max().item() + 1e-6
+    err = (got - want).abs().max().item()
+    assert err <= tol, f"{what}: max err {err:.4e} > {tol:.4e}"
+
+
+def test_swiglu_rmsnorm_tn_bwd():
+    from dualhyp_amd import ops
+    F = torch.nn.functional
+    rows, I, d = 37, 384, 256
+    g, u, dact = U((rows, I), 2.0, "g"), U((rows, I), 1.0, "u"), U((rows, I), 1.0, "da")
+    gf, uf = g.float().requires_grad_(), u.float().requires_grad_()
+    (F.silu(gf) * uf).backward(dact.float())
+    out = ops.swiglu_bwd(dact.to(DEV), g.to(DEV), u.to(DEV))
+    close(out[:, :I], gf.grad, "swiglu dg")
+    close(out[:, I:], uf.grad, "swiglu du")
+    # rmsnorm
+    x, w, dy, dres = U((rows, d), 2.0, "x"), (1 + U((d,), 0.25, "w").float()).bfloat16(), U((rows, d), 1.0, "dy"), U((rows, d), 1.0, "dr")
+    xf = x.float().requires_grad_()
+    y = w.float() * (xf * torch.rsqrt(torch.mean(xf * xf, -1, keepdim=True) + 1e-5))
+    y.backward(dy.float())
+    close(ops.rmsnorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), 1e-5), xf.grad, "rmsnorm dx")
+    close(ops.rmsnorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), 1e-5, dres=dres.to(DEV)), xf.grad + dres.float(), "rmsnorm dx + dres")
+    # token contraction (LoRA grads), accumulate into fp32
+    a, b = U((70, 48), 1.0, "ta"), U((70, 256), 1.0, "tb")
+    out = torch.ones((16, 256), dtype=torch.float32, device=DEV)
+    ops.tn_accum(a.to(DEV)[:, 16:32], b.to(DEV), out, scale=0.5, accumulate=True)
+    want = 1 + 0.5 * a[:, 16:32].float().T @ b.float()
+    assert (out.cpu() - want).abs().max().item() <= 1e-4 * want.abs().max().item()
+    ops.tn_accum(a.to(DEV)[:, 16:32], b.to(DEV), out, scale=2.0, accumulate=False)
+    assert (out.cpu() - 2 * (want - 1) / 0.5).abs().max().item() <= 1e-3
+
+
+@pytest.mark.parametrize("hs,n_head,n_groups", [(64, 32, 4), (64, 4, 2), (128, 8, 2)])
+def test_rope_and_attention_bwd(hs, n_head, n_groups):
+    from dualhyp_amd import ops
+    from oracle import ger_oracle as O
+    F = torch.nn.functional
+    qpk = n_head // n_groups
+    lens = [70, 33, 1, 128]
+    n_tok, s_max = sum(lens), 128
+    width = (n_head + 2 * n_groups) * hs
+    qkv = U((n_tok, width), 1.0, f"bq{hs}")
+    dout = U((n_tok, n_head * hs), 1.0, f"bdo{hs}")
+    cos, sin = O.build_rope_cache(s_max, hs)
+    i32 = torch.int32
+    slot = torch.cat([torch.full((n,), i, dtype=i32) for i, n in enumerate(lens)]).to(DEV)
+    pos = torch.cat([torch.arange(n, dtype=i32) for n in lens]).to(DEV)
+    starts = torch.tensor([sum(lens[:i]) for i in range(len(lens))], dtype=i32, device=DEV)
+    qlen = torch.tensor(lens, dtype=i32, device=DEV)
+    B = len(lens)
+    kc = torch.zeros((B, n_groups, s_max, hs), dtype=torch.bfloat16, device=DEV)
+    vt = torch.zeros((B, n_groups, hs, s_max), dtype=torch.bfloat16, device=DEV)
+    k_out = torch.empty((n_tok, n_groups, hs), dtype=torch.bfloat16, device=DEV)
+    v_out = torch.empty_like(k_out)
+    q = ops.qkv_rope_cache(qkv.to(DEV), cos.to(DEV), sin.to(DEV), slot, pos, kc, vt, n_head, n_groups, k_out=k_out, v_out=v_out)
+    lse = torch.empty((n_tok, n_head), dtype=torch.float32, device=DEV)
+    y = ops.attn_prefill(q, kc, vt, torch.arange(B, dtype=i32, device=DEV), starts, qlen, torch.zeros(B, dtype=i32, device=DEV),
+                         max(lens), lse=lse)
+    dq, dk, dv = ops.attn_bwd(q, k_out, v_out, y, dout.to(DEV), lse, starts, qlen, max(lens))
+    dqkv = ops.qkv_rope_bwd(dq, dk, dv, cos.to(DEV), sin.to(DEV), pos)
+    # reference: fp32 autograd through split + rope + SDPA, per sequence
+    t0 = 0
+    for n in lens:
+        x = qkv[t0:t0 + n].float().requires_grad_()
+        x5 = x.view(1, n, n_groups, qpk + 2, hs).permute(0, 2, 3, 1, 4)
+        qq, kk, vv = x5.split((qpk, 1, 1), dim=2)
+        qq = qq.reshape(1, -1, n, hs)
+        kk = kk.expand(1, n_groups, qpk, n, hs).reshape(1, -1, n, hs)
+        vv = vv.expand(1, n_groups, qpk, n, hs).reshape(1, -1, n, hs)
+        c, s = cos[:n].float(), sin[:n].float()
+        qq, kk = O.apply_rope(qq, c, s), O.apply_rope(kk, c, s)
+        o = F.scaled_dot_product_attention(qq, kk, vv, is_causal=True, scale=1 / math.sqrt(hs)).transpose(1, 2).reshape(n, -1)
+        lse_ref = torch.logsumexp((qq @ kk.transpose(-1, -2) / math.sqrt(hs)).masked_fill(~torch.tril(torch.ones(n, n, dtype=torch.bool)), -1e30), -1)
+        assert (lse[t0:t0 + n].cpu() - lse_ref[0].T).abs().max().item() < 2e-2, "forward log-sum-exp"
+        o.backward(dout[t0:t0 + n].float())
+        close(dqkv[t0:t0 + n], x.grad, f"d(qkv) seq len {n}", rel=2e-2)
+        t0 += n
