@@ -44,6 +44,7 @@ SIGNATURES = {
     "dh_finish_norm_bf16": (I, [P, I, I, I, I, P, F, P, P, P, P, F, P, P]),
     "dh_attn_decode_fused_bf16": (I, [P, I, I, I, I, P, F, I, I, P, P, P, P, P, P, P, I, I, I, I, P]),
     "dh_attn_prefill_bf16": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
+    "dh_swiglu_fwd_bf16": (I, [P, P, P, I64, P]),
     "dh_swiglu_bwd_bf16": (I, [P, P, P, P, I, I, P]),
     "dh_rmsnorm_bwd_bf16": (I, [P, P, P, P, P, I, I, F, P]),
     "dh_qkv_rope_bwd_bf16": (I, [P, P, P, P, P, P, P, I, I, I, I, P]),

@@ -35,6 +35,23 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restric
     }
 }
 
+// act = bf16( bf16(silu(g)) * u ) from separately stored g, u (the training forward keeps both)
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ u,
+                                                         bf16_t* __restrict__ act, size_t n8) {
+    for (size_t c = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c < n8; c += (size_t)gridDim.x * blockDim.x) {
+        const uint4 gv = reinterpret_cast<const uint4*>(g)[c], uv = reinterpret_cast<const uint4*>(u)[c];
+        const bf16_t *gp = (const bf16_t*)&gv, *up = (const bf16_t*)&uv;
+        uint4 o;
+        bf16_t* op = (bf16_t*)&o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float gg = bf2f(gp[e]);
+            op[e] = f2bf(rbf(gg / (1.0f + expf(-gg))) * bf2f(up[e]));
+        }
+        reinterpret_cast<uint4*>(act)[c] = o;
+    }
+}
+
 // ---------------------------------------------------------------------------------- RMSNorm backward
 // y = w * x * r, r = rsqrt(mean(x^2)+eps):  dx = r * (w*dy) - x * r^3 * mean(x * w*dy)   (+ dres)
 // one wave per row, row in registers.  dx_out = bf16(dx + dres) when dres != null.
@@ -127,12 +144,8 @@ __global__ __launch_bounds__(256) void qkv_rope_bwd_kernel(const bf16_t* __restr
 __global__ __launch_bounds__(256) void tn_accum_kernel(const bf16_t* __restrict__ a, int lda, const bf16_t* __restrict__ b,
                                                        int ldb, float* __restrict__ out, int ldo, int T, int M, int N,
                                                        float scale, int accumulate) {
-    __shared__ float red[4][16][17];
-    const int m0 = blockIdx.x * 16, n0 = blockIdx.y * 16;
-    const int tid = threadIdx.x, lm = tid & 15, ln = (tid >> 4) & 15 & 15;
-    // 256 threads = 16 (m) x 16 (n); every thread walks all tokens (coalescing across lm for a, ln for b)
-    const int m = m0 + lm, n = n0 + (tid >> 4);
-    (void)ln; (void)red;
+    // 256 threads = 16 (m) x 16 (n); every thread walks all tokens (a coalesces across m, b broadcasts)
+    const int m = blockIdx.x * 16 + (threadIdx.x & 15), n = blockIdx.y * 16 + (threadIdx.x >> 4);
     float acc = 0.f;
     if (m < M && n < N)
         for (int t = 0; t < T; ++t) acc = fmaf(bf2f(a[(size_t)t * lda + m]), bf2f(b[(size_t)t * ldb + n]), acc);
@@ -162,6 +175,14 @@ extern "C" int dh_swiglu_bwd_bf16(const dh_bf16* dact, const dh_bf16* g, const d
     DH_CHECK(dact && g && u && dgu && rows >= 0 && I % 8 == 0, "dh_swiglu_bwd_bf16: bad argument");
     if (rows == 0) return 0;
     hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, dact, g, u, dgu, (size_t)rows, I);
+    DH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dh_swiglu_fwd_bf16(const dh_bf16* g, const dh_bf16* u, dh_bf16* act, int64_t n, void* stream) {
+    DH_CHECK(g && u && act && n % 8 == 0, "dh_swiglu_fwd_bf16: bad argument");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, g, u, act, (size_t)(n / 8));
     DH_LAUNCH_CHECK();
     return 0;
 }

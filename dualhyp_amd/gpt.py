@@ -135,7 +135,9 @@ class LoRALinear(LoRALayer):
 
     def padded_lora(self) -> Tuple[torch.Tensor, torch.Tensor]:
         """(A [16, in], B [out, 16]) contiguous, rank zero-padded."""
-        return _pad_rank(self.lora_A.data, self.r, 0).contiguous(), _pad_rank(self.lora_B.data, self.r, 1).contiguous()
+        bf = torch.bfloat16   # LoRA parameters may be fp32 masters while fine-tuning; kernels take bf16
+        return (_pad_rank(self.lora_A.data.to(bf), self.r, 0).contiguous(),
+                _pad_rank(self.lora_B.data.to(bf), self.r, 1).contiguous())
 
     def merge(self) -> None:
         """W += (B A) * scaling (ger/lora.py:152-157)."""
@@ -185,11 +187,12 @@ class LoRAQKVLinear(LoRALinear):
     def padded_lora(self) -> Tuple[torch.Tensor, torch.Tensor]:
         """(A [48, in], B [out, 16]); disabled q/k/v segments are zero rows, which reproduces
         zero_pad (ger/lora.py:272-312) exactly."""
+        bf = torch.bfloat16
         if self.r == 16 and all(self.enable_lora):
-            return self.lora_A.data.contiguous(), self.lora_B.data.contiguous()
+            return self.lora_A.data.to(bf).contiguous(), self.lora_B.data.to(bf).contiguous()
         d_in, r = self.linear.in_features, self.r
-        A = self.lora_A.data.new_zeros(48, d_in)
-        B = self.lora_B.data.new_zeros(self.linear.out_features, 16)
+        A = torch.zeros(48, d_in, dtype=bf, device=self.lora_A.device)
+        B = torch.zeros(self.linear.out_features, 16, dtype=bf, device=self.lora_B.device)
         seg_rows = (d_in, self.kv_embd_size, self.kv_embd_size)
         a_off = b_off = row0 = 0
         for seg, en in enumerate(self.enable_lora):
@@ -442,7 +445,9 @@ class GPT(nn.Module):
 
     # ---- engine management -----------------------------------------------------------------
     def _param_signature(self) -> Tuple:
-        return tuple((p.data_ptr(), p.dtype, str(p.device)) for p in self.parameters())
+        # data_ptr + version: in-place updates of LoRA parameters (optimizer steps) invalidate the
+        # engine's rank-padded copies too
+        return tuple((p.data_ptr(), p.dtype, str(p.device), p._version) for p in self.parameters())
 
     def _drop_engine(self) -> None:
         if getattr(self, "_engine", None) is not None:

@@ -195,6 +195,12 @@ def vcache_to_plain(vt: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------ training backward
+def swiglu_fwd(g: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
+    act = torch.empty_like(g)
+    check(_lib.load().dh_swiglu_fwd_bf16(_p(_dev(g)), _p(_dev(u)), _p(act), g.numel(), _stream()))
+    return act
+
+
 def swiglu_bwd(dact: torch.Tensor, g: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
     rows, I = g.shape
     out = torch.empty((rows, 2 * I), dtype=torch.bfloat16, device=g.device)

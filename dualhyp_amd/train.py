@@ -1,0 +1,263 @@
+"""LoRA fine-tune path of the decoder (finetune/ger.py:212-353) on the HIP kernels.
+
+`forward_train` is what `GPT.forward` dispatches to when gradients are enabled: the no-cache forward
+of ger/lora.py:538-549 built from the same kernels as inference (tiled MFMA GEMMs with the fused
+LoRA epilogue, RMSNorm, rope, flash attention) while keeping the activations the backward needs;
+its autograd node runs the hand-written backward kernels (csrc/train_kernels.hip,
+csrc/attention_bwd.hip) plus the dX GEMMs on transposed copies of the frozen weights, and returns
+gradients for the LoRA parameters only — the base model is frozen
+(`mark_only_lora_as_trainable`, ger/lora.py:405-439), so no dW of a dense layer is ever formed.
+
+Numerics: activations and activation gradients are bf16 (the kernels' rounding points are those of
+the reference's bf16 forward); LoRA gradients are accumulated in fp32.  The reference's fine-tune runs
+under bf16-mixed autocast (fp32 residual stream); DESIGN.md lists that as a documented difference.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import torch
+
+from . import ops
+from .gpt import GPT, LoRALinear, LoRAQKVLinear, _pad_rank
+
+BF = torch.bfloat16
+
+
+class _Frozen:
+    """Transposed copies of the frozen weights for the dX GEMMs (y = x W^T  =>  dx = dy W, computed as
+    dy · (W^T)^T by the same K-contiguous NT kernels).  Built once; 1x the model's size in HBM."""
+
+    def __init__(self, model: GPT) -> None:
+        self.sig = tuple(p.data_ptr() for n, p in model.named_parameters() if "lora_" not in n)
+        self.lm_T = model.lm_head.linear.weight.data.t().contiguous()                      # [d, V]
+        self.layers = []
+        for blk in model.transformer.h:
+            w1, w2 = blk.mlp.fc_1.linear.weight.data, blk.mlp.fc_2.linear.weight.data
+            self.layers.append(dict(
+                qkv_T=blk.attn.attn.linear.weight.data.t().contiguous(),                    # [d, qkv]
+                proj_T=blk.attn.proj.linear.weight.data.t().contiguous(),                   # [d, d]
+                w12_T=torch.cat([w1, w2], dim=0).t().contiguous(),                          # [d, 2I]
+                mlp_T=blk.mlp.proj.linear.weight.data.t().contiguous(),                     # [I, d]
+            ))
+
+
+def _frozen(model: GPT) -> _Frozen:
+    fz = getattr(model, "_train_frozen", None)
+    sig = tuple(p.data_ptr() for n, p in model.named_parameters() if "lora_" not in n)
+    if fz is None or fz.sig != sig:
+        fz = _Frozen(model)
+        model._train_frozen = fz
+    return fz
+
+
+def lora_parameters(model: GPT) -> List[torch.nn.Parameter]:
+    """The trainable tensors in the fixed order the autograd node uses."""
+    out = []
+    for blk in model.transformer.h:
+        for m in (blk.attn.attn, blk.attn.proj):
+            if getattr(m, "r", 0) > 0 and hasattr(m, "lora_A"):
+                out += [m.lora_A, m.lora_B]
+    return out
+
+
+def prepare_for_training(model: GPT) -> List[torch.nn.Parameter]:
+    """bf16 frozen base + fp32 LoRA masters (what bf16-mixed keeps in fp32 and actually updates)."""
+    from .gpt import mark_only_lora_as_trainable
+    mark_only_lora_as_trainable(model)
+    ps = lora_parameters(model)
+    for p in ps:
+        p.data = p.data.float()
+        p.requires_grad_(True)
+    model._drop_engine()
+    return ps
+
+
+class _Layer:
+    __slots__ = ("x", "n1", "n1d", "xa", "q", "k", "v", "y", "lse", "xa2", "yd", "x1", "n2", "g", "u", "act", "mask1", "mask2")
+
+
+def _drop(x: torch.Tensor, p: float, training: bool):
+    """LoRA-branch dropout (ger/lora.py:96,165,391): mask scaled by 1/(1-p), result rounded to bf16."""
+    if not training or p <= 0.0:
+        return x, None
+    mask = (torch.rand(x.shape, device=x.device) >= p).to(BF) * (1.0 / (1.0 - p))
+    return x * mask, mask
+
+
+class _DecoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model: GPT, idx: torch.Tensor, *lora_ps: torch.Tensor) -> torch.Tensor:
+        cfg = model.config
+        dev = idx.device
+        B, T = idx.shape
+        n_tok = B * T
+        d, H, G, hs = cfg.n_embd, cfg.n_head, cfg.n_query_groups, cfg.head_size
+        i32 = torch.int32
+        if model.rope_cache is None or model.rope_cache[0].device != dev:
+            model.rope_cache = model.build_rope_cache(idx)
+        cos, sin = model.rope_cache
+        tail = None
+        V = model.cpu_rsqrt_vec_width
+        if V:
+            tail = (torch.arange(n_tok, device=dev) >= n_tok // V * V).to(torch.uint8)
+        tok_slot = torch.arange(B, dtype=i32, device=dev).repeat_interleave(T)
+        tok_pos = torch.arange(T, dtype=i32, device=dev).repeat(B)
+        seq_slot = torch.arange(B, dtype=i32, device=dev)
+        q_start = seq_slot * T
+        q_len = torch.full((B,), T, dtype=i32, device=dev)
+        zeros = torch.zeros(B, dtype=i32, device=dev)
+        s_max = -(-T // 64) * 64
+        kc = torch.zeros((B, G, s_max, hs), dtype=BF, device=dev)       # scratch, reused by every layer
+        vt = torch.zeros((B, G, hs, s_max), dtype=BF, device=dev)
+        p_drop, training = cfg.dropout, model.training
+        saved: List[_Layer] = []
+        x = ops.embed(idx.reshape(-1), model.transformer.wte.weight.data)
+        for blk in model.transformer.h:
+            L = _Layer()
+            qkv_m, proj_m = blk.attn.attn, blk.attn.proj
+            L.x = x
+            L.n1 = ops.rmsnorm(x, blk.norm_1.weight.data, cfg.norm_eps, row_tail=tail)
+            if qkv_m.lora_active:
+                A48, B16 = qkv_m.padded_lora()
+                L.n1d, L.mask1 = _drop(L.n1, p_drop, training)
+                L.xa = ops.linear(L.n1d, A48)
+                qkv = ops.linear(L.n1, qkv_m.linear.weight.data, epilogue=ops.EPI_LORA, xa=L.xa, lora_b=B16,
+                                 lora_scale=qkv_m.scaling, splits=qkv_m.splits)
+            else:
+                L.n1d = L.mask1 = L.xa = None
+                qkv = ops.linear(L.n1, qkv_m.linear.weight.data)
+            L.k = torch.empty((n_tok, G, hs), dtype=BF, device=dev)
+            L.v = torch.empty_like(L.k)
+            L.q = ops.qkv_rope_cache(qkv, cos, sin, tok_slot, tok_pos, kc, vt, H, G, k_out=L.k, v_out=L.v)
+            L.lse = torch.empty((n_tok, H), dtype=torch.float32, device=dev)
+            L.y = ops.attn_prefill(L.q, kc, vt, seq_slot, q_start, q_len, zeros, T, lse=L.lse)
+            if proj_m.lora_active:
+                Ap, Bp = proj_m.padded_lora()
+                L.yd, L.mask2 = _drop(L.y, p_drop, training)
+                L.xa2 = ops.linear(L.yd, Ap)
+                L.x1 = ops.linear(L.y, proj_m.linear.weight.data, epilogue=ops.EPI_LORA, xa=L.xa2, lora_b=Bp,
+                                  lora_scale=proj_m.scaling, resid=x)
+            else:
+                L.yd = L.mask2 = L.xa2 = None
+                L.x1 = ops.linear(L.y, proj_m.linear.weight.data, resid=x)
+            L.n2 = ops.rmsnorm(L.x1, blk.norm_2.weight.data, cfg.norm_eps, row_tail=tail)
+            L.g = ops.linear(L.n2, blk.mlp.fc_1.linear.weight.data)
+            L.u = ops.linear(L.n2, blk.mlp.fc_2.linear.weight.data)
+            L.act = ops.swiglu_fwd(L.g, L.u)
+            x = ops.linear(L.act, blk.mlp.proj.linear.weight.data, resid=L.x1)
+            saved.append(L)
+        xf = ops.rmsnorm(x, model.transformer.ln_f.weight.data, cfg.norm_eps, row_tail=tail)
+        logits = ops.linear(xf, model.lm_head.linear.weight.data, epilogue=ops.EPI_ADAPTER,
+                            scale=model.lm_head.adapter_scale.data, bias=model.lm_head.adapter_bias.data)
+        ctx.model, ctx.saved, ctx.x_last = model, saved, x
+        ctx.meta = (B, T, cos, sin, tok_pos, q_start, q_len)
+        ctx.param_dtypes = [p.dtype for p in lora_ps]
+        return logits.view(B, T, -1)
+
+    @staticmethod
+    def backward(ctx, dlogits: torch.Tensor):
+        model: GPT = ctx.model
+        cfg = model.config
+        B, T, cos, sin, tok_pos, q_start, q_len = ctx.meta
+        d, H, G, hs, I = cfg.n_embd, cfg.n_head, cfg.n_query_groups, cfg.head_size, cfg.intermediate_size
+        fz = _frozen(model)
+        dev = dlogits.device
+        dz = dlogits.reshape(B * T, -1).to(BF)
+        scale_vec = model.lm_head.adapter_scale.data
+        if not bool((scale_vec == 1).all()):
+            dz = dz * scale_vec                                        # d(scale*(z+bias))/dz
+        dz = dz.contiguous()
+        dxf = ops.linear(dz, fz.lm_T)
+        dx = ops.rmsnorm_bwd(dxf, ctx.x_last, model.transformer.ln_f.weight.data, cfg.norm_eps)
+        grads: List[Optional[torch.Tensor]] = []
+        per_layer: List[List[Optional[torch.Tensor]]] = []
+        for li in range(cfg.n_layer - 1, -1, -1):
+            blk, L, W = model.transformer.h[li], ctx.saved[li], fz.layers[li]
+            qkv_m, proj_m = blk.attn.attn, blk.attn.proj
+            # ---- MLP: x2 = x1 + proj(silu(fc_1 n2) * fc_2 n2)
+            dact = ops.linear(dx, W["mlp_T"])
+            dgu = ops.swiglu_bwd(dact, L.g, L.u)
+            dn2 = ops.linear(dgu, W["w12_T"])
+            dx1 = ops.rmsnorm_bwd(dn2, L.x1, blk.norm_2.weight.data, cfg.norm_eps, dres=dx)
+            # ---- attention output projection (+LoRA): x1 = x + y Wp^T + s (drop(y) Ap^T) Bp^T
+            gA2 = gB2 = None
+            if proj_m.lora_active:
+                s = proj_m.scaling
+                Ap, Bp = proj_m.padded_lora()                           # [16,d], [d,16]
+                t = ops.linear(dx1, Bp.t().contiguous())                # dx1 · Bp           [n,16]
+                if L.mask2 is None:
+                    dy = ops.linear(dx1, W["proj_T"], epilogue=ops.EPI_LORA, xa=t, lora_b=Ap.t().contiguous(), lora_scale=s)
+                else:
+                    lo = ops.linear(_pad64(t), _pad64(Ap.t().contiguous()))
+                    dy = ops.linear(dx1, W["proj_T"], resid=(lo * L.mask2 * s).contiguous())
+                gB2 = torch.zeros((d, 16), dtype=torch.float32, device=dev)
+                gA2 = torch.zeros((16, d), dtype=torch.float32, device=dev)
+                ops.tn_accum(dx1, L.xa2, gB2, scale=s, accumulate=False)
+                ops.tn_accum(t, L.yd, gA2, scale=s, accumulate=False)
+            else:
+                dy = ops.linear(dx1, W["proj_T"])
+            # ---- attention + rope
+            dq, dk, dv = ops.attn_bwd(L.q, L.k, L.v, L.y, dy, L.lse, q_start, q_len, T)
+            dqkv = ops.qkv_rope_bwd(dq, dk, dv, cos, sin, tok_pos)
+            # ---- fused qkv projection (+LoRA, contiguous [Q|K|V] delta placement, quirk Q2)
+            gA1 = gB1 = None
+            if qkv_m.lora_active:
+                s = qkv_m.scaling
+                A48, B16 = qkv_m.padded_lora()                          # [48,d], [qkv,16]
+                qd = B16.size(0)
+                s0, s1 = qkv_m.splits
+                bounds = (0, s0, s1, qd)
+                Bblk = torch.zeros((64, qd), dtype=BF, device=dev)      # block-structured B^T, rank slots 48..63 zero
+                for seg in range(3):
+                    Bblk[16 * seg:16 * seg + 16, bounds[seg]:bounds[seg + 1]] = B16[bounds[seg]:bounds[seg + 1]].t()
+                t3 = ops.linear(dqkv, Bblk)                              # [n,64], cols 16seg.. = dqkv[:,seg] · B_seg
+                lo = ops.linear(t3, _pad64(A48.t().contiguous()))        # [n,d] = t3 · A48
+                lo = lo * s if L.mask1 is None else lo * L.mask1 * s
+                dn1 = ops.linear(dqkv, W["qkv_T"], resid=lo.contiguous())
+                gB1 = torch.zeros((qd, 16), dtype=torch.float32, device=dev)
+                for seg in range(3):
+                    ops.tn_accum(dqkv[:, bounds[seg]:bounds[seg + 1]], L.xa[:, 16 * seg:16 * seg + 16],
+                                 gB1[bounds[seg]:bounds[seg + 1]], scale=s, accumulate=False)
+                gA1 = torch.zeros((48, d), dtype=torch.float32, device=dev)
+                ops.tn_accum(t3[:, :48], L.n1d, gA1, scale=s, accumulate=False)
+            else:
+                dn1 = ops.linear(dqkv, W["qkv_T"])
+            dx = ops.rmsnorm_bwd(dn1, L.x, blk.norm_1.weight.data, cfg.norm_eps, dres=dx1)
+            # ---- map the rank-padded gradients back onto the parameters' shapes
+            lg: List[Optional[torch.Tensor]] = []
+            if qkv_m.lora_active:
+                r, en = qkv_m.r, qkv_m.enable_lora
+                lg.append(torch.cat([gA1[16 * seg:16 * seg + r] for seg in range(3) if en[seg]], dim=0))
+                s0, s1 = qkv_m.splits
+                bounds = (0, s0, s1, gB1.size(0))
+                lg.append(torch.cat([gB1[bounds[seg]:bounds[seg + 1], :r] for seg in range(3) if en[seg]], dim=0))
+            if proj_m.lora_active:
+                lg += [gA2[:proj_m.r], gB2[:, :proj_m.r]]
+            per_layer.append(lg)
+            ctx.saved[li] = None                                         # free this layer's activations
+        for lg in reversed(per_layer):
+            grads += lg
+        grads = [g.to(dt) if g is not None else None for g, dt in zip(grads, ctx.param_dtypes)]
+        return (None, None, *grads)
+
+
+def _pad64(t: torch.Tensor) -> torch.Tensor:
+    """Zero-pad the contraction (last) dimension to a multiple of 64 (the GEMM kernels' K granule)."""
+    k = t.size(-1)
+    if k % 64 == 0:
+        return t.contiguous()
+    out = t.new_zeros((*t.shape[:-1], -(-k // 64) * 64))
+    out[..., :k] = t
+    return out
+
+
+def forward_train(model: GPT, idx: torch.Tensor, lm_head_chunk_size: int = 0) -> Union[torch.Tensor, List[torch.Tensor]]:
+    """Differentiable no-cache forward (ger/lora.py:538-549); gradients flow to the LoRA parameters."""
+    ps = lora_parameters(model)
+    assert ps, "forward_train: the model has no active LoRA parameters to train"
+    logits = _DecoderFn.apply(model, idx, *ps)
+    if lm_head_chunk_size > 0:
+        return list(logits.split(lm_head_chunk_size, dim=1))
+    return logits

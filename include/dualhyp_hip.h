@@ -146,6 +146,8 @@ int dh_attn_decode_fused_bf16(const float* qkv32, int n_part, int n_seq, int qkv
  * finetune/ger.py:278-285 `fabric.backward(loss / accum)` for the frozen-base / LoRA-only case: the dX
  * GEMMs reuse dh_linear_bf16 on transposed copies of the frozen weights; these are the rest. */
 
+/* act = bf16(bf16(silu(g)) * u) from stored g, u (training forward keeps both; ger/model.py:315) */
+int dh_swiglu_fwd_bf16(const dh_bf16* g, const dh_bf16* u, dh_bf16* act, int64_t n, void* stream);
 /* dgu[rows, 2I] = [dact*u*silu'(g) | dact*silu(g)]   (backward of ger/model.py:315) */
 int dh_swiglu_bwd_bf16(const dh_bf16* dact, const dh_bf16* g, const dh_bf16* u, dh_bf16* dgu, int rows,
                        int I, void* stream);

@@ -95,3 +95,50 @@ def test_rope_and_attention_bwd(hs, n_head, n_groups):
         o.backward(dout[t0:t0 + n].float())
         close(dqkv[t0:t0 + n], x.grad, f"d(qkv) seq len {n}", rel=2e-2)
         t0 += n
+
+
+@pytest.mark.parametrize("name", ["tiny_r4", "tiny_hs128_r16"])
+def test_train_micro_step_matches_reference(golden, name):
+    """One fine-tune micro-step (finetune/ger.py:278-285) through GPT.forward under autograd: loss and
+    every LoRA gradient against what the REFERENCE's autograd produced (tests/golden, bf16 run; the fp32
+    run of the same weights is the yardstick for what bf16 noise does to these gradients)."""
+    from dualhyp_amd import GPT, Config, chunked_cross_entropy
+    from dualhyp_amd.synth import synth_state_dict
+    from dualhyp_amd.train import prepare_for_training
+    t, meta = golden(name)
+    cfg = Config(**meta["config"])
+    sd = synth_state_dict(cfg, seed=meta["seed"], norm_jitter=meta["norm_jitter"], weight_scale=meta["weight_scale"], device=DEV)
+    m = GPT(cfg).to(device=DEV, dtype=torch.bfloat16)
+    m.load_state_dict(sd)
+    m.train()
+    params = prepare_for_training(m)
+    assert all(p.dtype == torch.float32 and p.requires_grad for p in params)
+    idx = torch.stack([t["idx0"], t["idx1"]]).to(DEV)
+    labels = t["train_labels"].to(DEV)
+    logits = m(idx, lm_head_chunk_size=8)
+    assert isinstance(logits, list) and logits[0].requires_grad
+    logits[-1] = logits[-1][..., :-1, :]
+    loss = chunked_cross_entropy(logits, labels[..., 1:], chunk_size=8)
+    (loss / 32).backward()
+    ref_loss, f32_loss = t["bf16.train_loss"].float().item(), t["fp32.train_loss"].item()
+    assert abs(loss.item() - f32_loss) <= max(2 * abs(ref_loss - f32_loss), 2e-2), (loss.item(), ref_loss, f32_loss)
+    worst = 0.0
+    for n, p in m.named_parameters():
+        if "lora_" not in n:
+            assert p.grad is None
+            continue
+        g32, gbf = t[f"fp32.grad.{n}"].float(), t[f"bf16.grad.{n}"].float()
+        got = p.grad.float().cpu()
+        assert got.shape == g32.shape
+        scale = g32.abs().max().item()
+        e_hip, e_ref = (got - g32).abs().max().item() / scale, (gbf - g32).abs().max().item() / scale
+        worst = max(worst, e_hip)
+        # HIP's distance to the exact (fp32) gradient within 2x the reference-bf16 run's own, or 3% of max
+        assert e_hip <= max(2.0 * e_ref, 0.03), f"{n}: hip {e_hip:.3f} vs reference-bf16 {e_ref:.3f} of max|g|"
+    print(f"[parity] {name} LoRA grads: worst distance to fp32 reference {worst:.3%} of max|g|")
+    # eval-mode forward under no_grad still goes through the engine
+    m.eval()
+    with torch.no_grad():
+        lg = m(idx)
+    val = chunked_cross_entropy(lg[..., :-1, :], labels[..., 1:], chunk_size=0)
+    assert abs(val.item() - t["fp32.val_loss"].item()) <= max(2 * abs(t["bf16.val_loss"].float().item() - t["fp32.val_loss"].item()), 5e-2)
