@@ -142,3 +142,36 @@ def test_train_micro_step_matches_reference(golden, name):
         lg = m(idx)
     val = chunked_cross_entropy(lg[..., :-1, :], labels[..., 1:], chunk_size=0)
     assert abs(val.item() - t["fp32.val_loss"].item()) <= max(2 * abs(t["bf16.val_loss"].float().item() - t["fp32.val_loss"].item()), 5e-2)
+
+
+def test_fit_reduces_loss_and_saves_reference_checkpoint(tmp_path):
+    """A few optimizer steps of the whole loop (AdamW on fp32 LoRA masters, flat grad bucket, LR warm-up,
+    validation through the inference engine, checkpoint in the reference's format)."""
+    from dualhyp_amd import GPT, Config
+    from dualhyp_amd.data import collate
+    from dualhyp_amd.finetune import TrainConfig, fit, validate
+    from dualhyp_amd.synth import synth_state_dict, hash_u24, stream_id
+    cfg = Config.from_name("parity-tiny", r=4, alpha=8, dropout=0.05, to_query=True, to_key=True, to_value=True, to_projection=True)
+    sd = synth_state_dict(cfg, seed=5, weight_scale=4.0, device=DEV)
+    m = GPT(cfg).to(device=DEV, dtype=torch.bfloat16)
+    m.load_state_dict(sd)
+    exs = []
+    for i in range(16):            # a learnable toy task: the response repeats a fixed pattern
+        T = 20 + i % 5
+        ids = (hash_u24(T, stream_id(9, f"ex{i}")) % 200 + 3)
+        ids[-6:] = torch.tensor([7, 8, 9, 7, 8, 2])
+        lab = ids.clone()
+        lab[:-6] = -1
+        exs.append({"input_ids": ids, "labels": lab, "input_ids_no_response": ids[:-6], "input": "", "uid": str(i), "ground_truth": ""})
+    val = lambda: [collate(exs[:4])]
+    val = lambda: [{k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in collate(exs[:4]).items()}]
+    v0 = validate(m, val())
+    tc = TrainConfig(learning_rate=2e-3, num_epochs=6, batch_size=4, micro_batch_size=2, lm_head_chunk_size=8)
+    out = fit(m, exs, collate, tc, val_batches=val, out_dir=str(tmp_path), device=DEV, log=lambda s: None)
+    assert out["optimizer_steps"] == 6 * 16 // 4
+    assert out["best_val_loss"] < 0.7 * v0, (v0, out)
+    ck = torch.load(tmp_path / "best_model.pth")
+    assert set(ck) == {"model"} and "transformer.h.1.attn.attn.lora_B" in ck["model"] and "lm_head.linear.weight" in ck["model"]
+    # the LoRA masters moved, the frozen base did not
+    assert not torch.equal(ck["model"]["transformer.h.0.attn.proj.lora_B"].float(), sd["transformer.h.0.attn.proj.lora_B"].float().cpu())
+    assert torch.equal(ck["model"]["transformer.h.0.mlp.fc_1.linear.weight"], sd["transformer.h.0.mlp.fc_1.linear.weight"].cpu())

@@ -142,3 +142,54 @@ def test_sharded_inference_matches_single_process():
         for k in ("WER", "gtms", "post_ST_wer", "post_gtms", "n"):
             assert got[r][k] == single[k], (r, k)
     assert got[0]["predictions"] == single["predictions"] and got[1]["predictions"] is None
+
+
+def test_lr_schedule_and_accumulation_trace():
+    from dualhyp_amd.finetune import lr_at, step_schedule, epoch_order
+    from oracle import ger_oracle as O
+    for it in (0, 5, 10, 11, 50, 99, 100, 250):
+        for cos in (False, True):
+            assert lr_at(it, 1e-4, 10, 100, cos, 0.1) == pytest.approx(O.lr_at(it, 1e-4, 10, 100, cos, 0.1))
+    assert lr_at(10, 1e-4, 10) == 1e-4 and lr_at(5, 1e-4, 10) == 5e-5 and lr_at(11, 1e-4, 10) == 1e-4
+    # quirk Q3: with accum 32 the reference steps after 31 micro-batches (indices 30, 61, 92, ...)
+    assert step_schedule(100, 32, reference_accumulation=True) == [30, 61, 92]
+    assert step_schedule(100, 32) == [31, 63, 95]
+    # sharded epoch order: ranks partition one permutation, equal sizes, different per epoch
+    a, b = epoch_order(11, 0, 0, 2), epoch_order(11, 0, 1, 2)
+    assert len(a) == len(b) == 5 and not set(a) & set(b) and epoch_order(11, 1, 0, 2) != a
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from dualhyp_amd.finetune import FlatGradBucket
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ps = [torch.nn.Parameter(torch.zeros(3, 4)), torch.nn.Parameter(torch.zeros(5))]
+    bkt = FlatGradBucket(ps)
+    assert bkt.flat.numel() == 17 and ps[0].grad.data_ptr() == bkt.flat.data_ptr()
+    # "backward" accumulates in place into the bucket views
+    ps[0].grad += (rank + 1)
+    ps[1].grad += 10 * (rank + 1)
+    bkt.all_reduce_mean()
+    q.put((rank, ps[0].grad.clone(), ps[1].grad.clone()))
+    bkt.zero()
+    assert float(bkt.flat.abs().sum()) == 0 and ps[1].grad.data_ptr() == bkt.flat[12:].data_ptr()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_bucket_allreduce_gloo():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, g0, g1 in got:
+        assert torch.all(g0 == 1.5) and torch.all(g1 == 15.0)       # mean over the two ranks
