@@ -53,6 +53,8 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--engines", type=int, default=2, help="batches in flight per GPU (dualhyp_amd.pipeline)")
+    ap.add_argument("--schedule", choices=("gang", "threads"), default="gang")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -68,7 +70,8 @@ def main() -> None:
         dist.init_process_group("nccl", device_id=dev)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
-    from dualhyp_amd import GPT, Config, GER_LORA, generate_batch
+    from dualhyp_amd import GPT, Config, GER_LORA
+    from dualhyp_amd.pipeline import BatchPipeline
     from dualhyp_amd.synth import synth_state_dict, synth_prompts
 
     cfg = Config.from_name("tiny-llama-1.1b-chat", **{**GER_LORA, "dropout": 0.0})
@@ -78,34 +81,45 @@ def main() -> None:
     del sd
     model.eval()
     B = a.batch
-    model.set_capacity(B, PROMPT_LEN + NEW_TOKENS, B * PROMPT_LEN)
+    # `engines` batches in flight: each engine has its own KV cache, workspace, decode graph and HIP
+    # stream and shares the one copy of the weights; a "step" is still ONE batch of B utterances
+    pipe = BatchPipeline(model, a.engines, B, PROMPT_LEN + NEW_TOKENS, B * PROMPT_LEN)
     # every rank gets its own utterances (strided shard of one synthetic corpus)
-    n_batches = a.steps + a.warmup
+    n_batches = a.steps + max(a.warmup, 1)
     corpus = synth_prompts(B * n_batches * world, PROMPT_LEN, cfg.padded_vocab_size, seed=1337)
     mine = [p.to(dev) for p in corpus[rank::world]]
 
-    def step(i: int):
-        return generate_batch(model, mine[i * B:(i + 1) * B], NEW_TOKENS, temperature=0.2, top_k=1, eos_id=None)
+    def submit(i: int):
+        return pipe.submit(mine[i * B:(i + 1) * B], NEW_TOKENS, temperature=0.2, top_k=1, eos_id=None)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(a.warmup):
-        step(i)
-    eng = model.engine()
-    eng.set_timing(True)
+    n_warm = max(a.warmup, 1)
+    pipe.warm(mine[:B], NEW_TOKENS, temperature=0.2, top_k=1, eos_id=None)   # every engine: alloc + graph capture
+    for f in [submit(i) for i in range(1, n_warm)]:
+        f.result()
+    engs = [m.engine() for m in pipe.models]
+    for e in engs:
+        e.set_timing(not os.environ.get("DUALHYP_NO_TIMING"))
     barrier()
     t0 = time.perf_counter()
-    for i in range(a.steps):
-        out = step(a.warmup + i)
+    timed = [mine[(n_warm + i) * B:(n_warm + i + 1) * B] for i in range(a.steps)]
+    if a.schedule == "gang":      # prefills exclusive, decode loops of `engines` batches concurrent
+        outs = pipe.run_gangs(timed, NEW_TOKENS, temperature=0.2, top_k=1, eos_id=None)
+    else:                         # free-running: one host thread per engine
+        outs = [f.result() for f in [submit(n_warm + i) for i in range(a.steps)]]
     barrier()
     dt = time.perf_counter() - t0
-    gemm_ms, gemm_n = eng.get_timing(0)
-    attn_ms, attn_n = eng.get_timing(2)
-    eng.set_timing(False)
-    assert all(o.numel() == PROMPT_LEN + NEW_TOKENS for o in out)
+    gemm_ms = gemm_n = attn_ms = 0
+    for e in engs:
+        ms, n = e.get_timing(0)
+        gemm_ms, gemm_n = gemm_ms + ms, gemm_n + n
+        attn_ms += e.get_timing(2)[0]
+        e.set_timing(False)
+    assert all(o.numel() == PROMPT_LEN + NEW_TOKENS for out in outs for o in out)
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -124,7 +138,7 @@ def main() -> None:
             "config": {"workload": "DualHyp inference, TinyLlama-1.1B bf16 + LoRA r16 (q,k,v,proj), batch 32/GPU "
                                    "synthetic 5+5-hyp prompts, 512-token prompt -> 64 generated tokens, greedy",
                        "batch_per_gpu": B, "prompt_tokens": PROMPT_LEN, "new_tokens": NEW_TOKENS,
-                       "parallelism": f"replicas x{world}"},
+                       "parallelism": f"replicas x{world}", "batches_in_flight_per_gpu": a.engines},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (prefill GEMMs: qkv+LoRA, proj+LoRA, fc_1/fc_2 SwiGLU, mlp proj)",
                          "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None,

@@ -42,7 +42,7 @@ struct dh_engine {
     int64_t dev_bytes = 0;
     // decode graph
     hipStream_t gstream = nullptr;
-    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_stage = nullptr;
     hipGraphExec_t gexec = nullptr;
     struct { int64_t* tokens; int tok_ld; int32_t *length, *done; int n_seq, top_k; float temp; int64_t eos; uint64_t seed; } gkey{};
     int last_ntok = 0;
@@ -75,6 +75,12 @@ __global__ void decode_prep_kernel(const int64_t* __restrict__ tokens, int tok_l
         kv_len[i] = n;
     }
     if (i == 0) *step_dev += 1;
+}
+
+__global__ void set_i32_kernel(int32_t* p, int32_t v) { *p = v; }
+__global__ void iota_i32_kernel(int32_t* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = i;
 }
 
 __global__ void gather_rows_kernel(const bf16_t* __restrict__ src, const int32_t* __restrict__ rows,
@@ -291,6 +297,9 @@ extern "C" int dh_engine_create(const dh_model_desc* desc, int max_batch, int s_
     DH_HIP(hipStreamCreateWithFlags(&e->gstream, hipStreamNonBlocking));
     DH_HIP(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
     DH_HIP(hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming));
+    DH_HIP(hipEventCreateWithFlags(&e->ev_stage, hipEventDisableTiming));
+    hipLaunchKernelGGL(iota_i32_kernel, dim3(cdiv(max_batch, 64)), dim3(64), 0, 0, e->seq_meta, max_batch);
+    DH_HIP(hipDeviceSynchronize());
     *out = e;
     return 0;
 }
@@ -307,6 +316,7 @@ extern "C" void dh_engine_destroy(dh_engine* e) {
     if (e->gstream) hipStreamDestroy(e->gstream);
     if (e->ev_in) hipEventDestroy(e->ev_in);
     if (e->ev_out) hipEventDestroy(e->ev_out);
+    if (e->ev_stage) hipEventDestroy(e->ev_stage);
     for (auto& v : e->tm.ev)
         for (auto& p : v) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     delete e;
@@ -350,7 +360,7 @@ extern "C" int dh_engine_forward(dh_engine* e, const int64_t* ids, const int32_t
     // metadata: [tok_slot | tok_pos | seq_slot | q_start | q_len | kv_pos0 | last_row]
     const int B = e->max_batch;
     int32_t* hs_ = e->h_stage;
-    DH_HIP(hipStreamSynchronize(s));   // the pinned staging buffer may still be in flight from the previous call
+    DH_HIP(hipEventSynchronize(e->ev_stage));   // this engine's previous metadata upload must have left the pinned buffer
     int32_t *h_slot = hs_, *h_pos = hs_ + e->max_tokens, *h_meta = hs_ + 2 * (size_t)e->max_tokens;
     int t = 0;
     for (int i = 0; i < n_seq; ++i) {
@@ -377,8 +387,10 @@ extern "C" int dh_engine_forward(dh_engine* e, const int64_t* ids, const int32_t
     }
     DH_HIP(hipMemcpyAsync(e->tok_slot, h_slot, n_tok * sizeof(int32_t), hipMemcpyHostToDevice, s));
     DH_HIP(hipMemcpyAsync(e->tok_pos, h_pos, n_tok * sizeof(int32_t), hipMemcpyHostToDevice, s));
-    DH_HIP(hipMemcpyAsync(e->seq_meta, h_meta, 4 * B * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    // seq_meta[0..B) (slot of sequence i = i) is written once at engine creation and left alone
+    DH_HIP(hipMemcpyAsync(e->seq_meta + B, h_meta + B, 3 * B * sizeof(int32_t), hipMemcpyHostToDevice, s));
     DH_HIP(hipMemcpyAsync(e->last_row, h_meta + 4 * B, B * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    DH_HIP(hipEventRecord(e->ev_stage, s));
     int rc;
     // one token per sequence == a decode step (what generate()'s loop issues): same kernels as dh_engine_decode
     const bool fast = max_q == 1 && n_seq <= 32 && e->d.n_embd % 16 == 0;
@@ -439,16 +451,10 @@ extern "C" int dh_engine_decode(dh_engine* e, int64_t* tokens, int tok_ld, int32
     DH_CHECK(temperature > 0.f && top_k >= 0, "dh_engine_decode: bad sampling parameters");
     if (n_steps <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    // seq_slot identity for the decode attention
-    {
-        DH_HIP(hipStreamSynchronize(s));
-        int32_t* h_meta = e->h_stage;
-        for (int i = 0; i < n_seq; ++i) h_meta[i] = i;
-        DH_HIP(hipMemcpyAsync(e->seq_meta, h_meta, n_seq * sizeof(int32_t), hipMemcpyHostToDevice, s));
-        int32_t fs = first_step;
-        h_meta[e->max_batch] = fs;
-        DH_HIP(hipMemcpyAsync(e->step_dev, h_meta + e->max_batch, sizeof(int32_t), hipMemcpyHostToDevice, s));
-    }
+    // seq_slot (seq_meta[0..B)) is the identity from engine creation on; nothing here touches the host
+    // staging buffer, so the call never waits for the stream (several engines can be driven back to back)
+    hipLaunchKernelGGL(set_i32_kernel, dim3(1), dim3(1), 0, s, e->step_dev, (int32_t)first_step);
+    DH_LAUNCH_CHECK();
     const bool same = e->gexec && e->gkey.tokens == tokens && e->gkey.tok_ld == tok_ld && e->gkey.length == length &&
                       e->gkey.done == done && e->gkey.n_seq == n_seq && e->gkey.top_k == top_k &&
                       e->gkey.temp == temperature && e->gkey.eos == eos_id && e->gkey.seed == seed;

@@ -121,6 +121,91 @@ __global__ __launch_bounds__(512, 2) void gemm_skinny_kernel(GemmArgs a) {
     a.y[(size_t)tm * a.N + nn] = f2bf(o);
 }
 
+// SwiGLU at decode, 32 row pairs per block: one pair of x fragments now feeds EIGHT MFMAs (two 16-row
+// tiles of fc_1 and of fc_2), halving the x share of the vector-load traffic that bounds this GEMM
+// (the x loads are L2 hits but ride the same load path as the HBM stream: 20.5 -> 13.6 us with them
+// removed entirely, tools/tune_decode.py).  K dealt over the 8 waves, partials meet in LDS (64 KiB).
+__global__ __launch_bounds__(512, 1) void swiglu_skinny2_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float part2x[];      // [fc 2][wave 8][m 32][n 32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * 32;
+    const int lrow = lane & 15, kg = lane >> 4;
+    int na = n0 + lrow, nb = n0 + 16 + lrow;
+    na = na < a.N ? na : a.N - 1;
+    nb = nb < a.N ? nb : a.N - 1;
+    const bf16_t* w1a = a.w + (size_t)na * a.K + kg * 8;
+    const bf16_t* w1b = a.w + (size_t)nb * a.K + kg * 8;
+    const bf16_t* w2a = a.w2 + (size_t)na * a.K + kg * 8;
+    const bf16_t* w2b = a.w2 + (size_t)nb * a.K + kg * 8;
+    int m_lo = lrow, m_hi = 16 + lrow;
+    m_lo = m_lo < a.M ? m_lo : a.M - 1;
+    m_hi = m_hi < a.M ? m_hi : a.M - 1;
+    const bf16_t* xlo = a.x + (size_t)m_lo * a.K + kg * 8;
+    const bf16_t* xhi = a.x + (size_t)m_hi * a.K + kg * 8;
+    f32x4 acc[2][2][2];                                    // [fc][row tile][m half]
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) acc[f][t][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int C2 = 4;
+    const int nks = a.K / 32;
+    for (int ks0 = wave; ks0 < nks; ks0 += NW * C2) {
+        bf16x8 f1a[C2], f1b[C2], f2a[C2], f2b[C2], xl[C2], xh[C2];
+#pragma unroll
+        for (int c = 0; c < C2; ++c) {
+            const int ks = ks0 + c * NW;
+            if (ks < nks) {
+                f1a[c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(w1a + ks * 32));
+                f1b[c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(w1b + ks * 32));
+                f2a[c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(w2a + ks * 32));
+                f2b[c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(w2b + ks * 32));
+                xl[c] = *reinterpret_cast<const bf16x8*>(xlo + ks * 32);
+                xh[c] = *reinterpret_cast<const bf16x8*>(xhi + ks * 32);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C2; ++c) {
+            const int ks = ks0 + c * NW;
+            if (ks < nks) {
+                acc[0][0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1a[c], xl[c], acc[0][0][0], 0, 0, 0);
+                acc[0][0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1a[c], xh[c], acc[0][0][1], 0, 0, 0);
+                acc[0][1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1b[c], xl[c], acc[0][1][0], 0, 0, 0);
+                acc[0][1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f1b[c], xh[c], acc[0][1][1], 0, 0, 0);
+                acc[1][0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f2a[c], xl[c], acc[1][0][0], 0, 0, 0);
+                acc[1][0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f2a[c], xh[c], acc[1][0][1], 0, 0, 0);
+                acc[1][1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f2b[c], xl[c], acc[1][1][0], 0, 0, 0);
+                acc[1][1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f2b[c], xh[c], acc[1][1][1], 0, 0, 0);
+            }
+        }
+    }
+    // C: col (m) = lrow (+16*h), rows (n) = 4*kg + reg (+16*t)
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                *reinterpret_cast<f32x4*>(&part2x[(((f * NW + wave) * 32) + 16 * h + lrow) * 32 + 16 * t + kg * 4]) = acc[f][t][h];
+    __syncthreads();
+    for (int it = tid; it < 32 * 32; it += 512) {
+        const int tn = it & 31, tm = it >> 5, nn = n0 + tn;
+        if (tm >= a.M || nn >= a.N) continue;
+        float g = 0.f, u = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            g += part2x[((0 * NW + w) * 32 + tm) * 32 + tn];
+            u += part2x[((1 * NW + w) * 32 + tm) * 32 + tn];
+        }
+        g = rbf(g);
+        u = rbf(u);
+        a.y[(size_t)tm * a.N + nn] = f2bf(rbf(g / (1.0f + expf(-g))) * u);
+    }
+}
+
+int g_swiglu2 = 1;
+
 // fp32 partial sums for consumers that finish the epilogue themselves (decode_fused.hip):
 //   part[by][m][n] = sum over the k-steps of K-slice `by` of x[m,:] . W'[n,:],  W' = [w ; w_ext]
 // grid (N'/16, ksplit): the 8*ksplit waves that share a row tile interleave over K, so small
@@ -275,11 +360,19 @@ extern "C" int dh_linear_partial_bf16(const dh_bf16* x, const dh_bf16* w, const 
 extern "C" int dh_set_tuning(int key, int value) {
     if (key == 0) { g_skinny_variant = value; return 0; }
     if (key == 1) { g_gemm_variant = value; return 0; }
+    if (key == 2) { g_swiglu2 = value; return 0; }
     dh_set_error("dh_set_tuning: unknown key %d", key);
     return 1;
 }
 
 int dh_linear_skinny(const GemmArgs& a, int epilogue, hipStream_t s) {
+    if (epilogue == DH_EPI_SWIGLU && g_swiglu2 && a.N % 32 == 0) {
+        static bool attr = false;
+        if (!attr) { DH_HIP(hipFuncSetAttribute((const void*)swiglu_skinny2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); attr = true; }
+        hipLaunchKernelGGL(swiglu_skinny2_kernel, dim3(a.N / 32), dim3(512), 64 * 1024, s, a);
+        DH_LAUNCH_CHECK();
+        return 0;
+    }
     switch (epilogue) {
         case DH_EPI_PLAIN: return launch<DH_EPI_PLAIN>(a, s);
         case DH_EPI_LORA: return launch<DH_EPI_LORA>(a, s);

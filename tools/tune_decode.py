@@ -45,8 +45,10 @@ for variant in (0, 1):
         print(f"variant {variant} mlp ks={ks}: {t:6.1f} us  {d*I*2/t/1e6:5.2f} TB/s")
 Wl = [torch.randn(32000, d, device=D).bfloat16() * 0.02 for _ in range(3)]
 sc = torch.ones(32000, device=D).bfloat16(); bi = torch.zeros(32000, device=D).bfloat16()
-t = bench(lambda i: ops.linear(x, W1[i % L], epilogue=ops.EPI_SWIGLU, w2=W2[i % L]))
-print(f"swiglu: {t:6.1f} us  {2*I*d*2/t/1e6:5.2f} TB/s")
+for v in (0, 1):
+    lib.dh_set_tuning(2, v)
+    t = bench(lambda i: ops.linear(x, W1[i % L], epilogue=ops.EPI_SWIGLU, w2=W2[i % L]))
+    print(f"swiglu (32-row variant={v}): {t:6.1f} us  {2*I*d*2/t/1e6:5.2f} TB/s")
 t = bench(lambda i: ops.linear(x, Wl[i % 3], epilogue=ops.EPI_ADAPTER, scale=sc, bias=bi))
 print(f"lm_head: {t:6.1f} us  {32000*d*2/t/1e6:5.2f} TB/s")
 
