@@ -50,11 +50,15 @@ def gemm_flops_per_prefill(cfg, n_tok: int, n_seq: int) -> float:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--engines", type=int, default=2, help="batches in flight per GPU (dualhyp_amd.pipeline)")
-    ap.add_argument("--schedule", choices=("gang", "threads"), default="gang")
+    ap.add_argument("--in-flight", type=int, default=4,
+                    help="batches (steps) decoded together per GPU: each batch of --batch prompts is prefilled on its "
+                         "own, then the decode loop runs over all in-flight sequences at once")
+    ap.add_argument("--schedule", choices=("merged", "threads"), default="merged",
+                    help="merged: one engine, chunked prefill + joint decode (generate_batch); threads: one engine, "
+                         "HIP stream and host thread per in-flight batch (dualhyp_amd.pipeline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -80,37 +84,53 @@ def main() -> None:
     model.load_state_dict(sd, strict=True)
     del sd
     model.eval()
-    B = a.batch
-    # `engines` batches in flight: each engine has its own KV cache, workspace, decode graph and HIP
-    # stream and shares the one copy of the weights; a "step" is still ONE batch of B utterances
-    pipe = BatchPipeline(model, a.engines, B, PROMPT_LEN + NEW_TOKENS, B * PROMPT_LEN)
+    B, G = a.batch, max(1, a.in_flight)
+    from dualhyp_amd.generate import generate_batch
+    gen_kw = dict(temperature=0.2, top_k=1, eos_id=None)
     # every rank gets its own utterances (strided shard of one synthetic corpus)
-    n_batches = a.steps + max(a.warmup, 1)
+    n_warm = max(a.warmup, 1)
+    n_batches = a.steps + n_warm
     corpus = synth_prompts(B * n_batches * world, PROMPT_LEN, cfg.padded_vocab_size, seed=1337)
     mine = [p.to(dev) for p in corpus[rank::world]]
-
-    def submit(i: int):
-        return pipe.submit(mine[i * B:(i + 1) * B], NEW_TOKENS, temperature=0.2, top_k=1, eos_id=None)
+    batches = [mine[i * B:(i + 1) * B] for i in range(n_batches)]
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    n_warm = max(a.warmup, 1)
-    pipe.warm(mine[:B], NEW_TOKENS, temperature=0.2, top_k=1, eos_id=None)   # every engine: alloc + graph capture
-    for f in [submit(i) for i in range(1, n_warm)]:
-        f.result()
-    engs = [m.engine() for m in pipe.models]
+    def run_merged(bs):
+        """a "step" is ONE batch of B utterances; up to G consecutive steps share a decode loop"""
+        outs = []
+        for g in range(0, len(bs), G):
+            flat = [p for b in bs[g:g + G] for p in b]
+            o = generate_batch(model, flat, NEW_TOKENS, prefill_batch=B, **gen_kw)
+            outs += [o[i:i + B] for i in range(0, len(o), B)]
+        return outs
+
+    if a.schedule == "merged":
+        # untimed: allocation + decode-graph capture at the in-flight size(s) the timed region uses
+        run_merged([batches[i % n_warm] for i in range(min(G, a.steps))])
+        if a.steps % G and a.steps > G:
+            run_merged([batches[0]] * (a.steps % G))
+        run_merged(batches[:n_warm])
+        engs = [model.engine()]
+    else:
+        # `in-flight` engines: each has its own KV cache, workspace, decode graph and HIP stream and
+        # shares the one copy of the weights
+        pipe = BatchPipeline(model, G, B, PROMPT_LEN + NEW_TOKENS, B * PROMPT_LEN)
+        pipe.warm(batches[0], NEW_TOKENS, **gen_kw)   # every engine: alloc + graph capture
+        for f in [pipe.submit(batches[i], NEW_TOKENS, **gen_kw) for i in range(1, n_warm)]:
+            f.result()
+        engs = [m.engine() for m in pipe.models]
     for e in engs:
-        e.set_timing(not os.environ.get("DUALHYP_NO_TIMING"))
+        e.set_timing(True)
     barrier()
     t0 = time.perf_counter()
-    timed = [mine[(n_warm + i) * B:(n_warm + i + 1) * B] for i in range(a.steps)]
-    if a.schedule == "gang":      # prefills exclusive, decode loops of `engines` batches concurrent
-        outs = pipe.run_gangs(timed, NEW_TOKENS, temperature=0.2, top_k=1, eos_id=None)
-    else:                         # free-running: one host thread per engine
-        outs = [f.result() for f in [submit(n_warm + i) for i in range(a.steps)]]
+    if a.schedule == "merged":
+        outs = run_merged(batches[n_warm:])
+    else:
+        outs = [f.result() for f in [pipe.submit(b, NEW_TOKENS, **gen_kw) for b in batches[n_warm:]]]
     barrier()
     dt = time.perf_counter() - t0
     gemm_ms = gemm_n = attn_ms = 0
@@ -138,7 +158,8 @@ def main() -> None:
             "config": {"workload": "DualHyp inference, TinyLlama-1.1B bf16 + LoRA r16 (q,k,v,proj), batch 32/GPU "
                                    "synthetic 5+5-hyp prompts, 512-token prompt -> 64 generated tokens, greedy",
                        "batch_per_gpu": B, "prompt_tokens": PROMPT_LEN, "new_tokens": NEW_TOKENS,
-                       "parallelism": f"replicas x{world}", "batches_in_flight_per_gpu": a.engines},
+                       "parallelism": f"replicas x{world}", "batches_in_flight_per_gpu": G, "schedule": a.schedule,
+                       "decode_rows_per_launch": B * min(G, a.steps) if a.schedule == "merged" else B},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (prefill GEMMs: qkv+LoRA, proj+LoRA, fc_1/fc_2 SwiGLU, mlp proj)",
                          "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None,

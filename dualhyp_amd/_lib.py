@@ -59,6 +59,7 @@ SIGNATURES = {
     "dh_engine_destroy": (None, [P]),
     "dh_engine_device_bytes": (I64, [P]),
     "dh_engine_forward": (I, [P, P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), I, P, P, P]),
+    "dh_engine_forward_at": (I, [P, P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), I, I, P, P, P]),
     "dh_engine_set_cpu_rsqrt_emulation": (I, [P, I, I]),
     "dh_engine_decode": (I, [P, P, I, P, P, I, I, F, I, I64, U64, I, P]),
     "dh_engine_read": (I, [P, I, I, P, I64, P]),

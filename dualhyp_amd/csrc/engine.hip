@@ -21,6 +21,8 @@ struct Timing {
 
 }  // namespace
 
+constexpr int MAX_DECODE_ROWS = 256;   // single-token calls up to here take the 7-launch streaming path
+
 struct dh_engine {
     dh_model_desc d;
     std::vector<dh_layer_weights> layers;
@@ -46,6 +48,7 @@ struct dh_engine {
     hipGraphExec_t gexec = nullptr;
     struct { int64_t* tokens; int tok_ld; int32_t *length, *done; int n_seq, top_k; float temp; int64_t eos; uint64_t seed; } gkey{};
     int last_ntok = 0;
+    int slot_base = 0;         // first KV-cache slot of the sequences of the current forward call
     bool capturing = false;   // no event records inside a stream capture
     bool phase_decode = false; // single-token-per-sequence call: weight-streaming GEMMs + split-KV attention
     Timing tm;
@@ -110,7 +113,7 @@ int linear(dh_engine* e, const bf16_t* x, const bf16_t* w, bf16_t* y, int M, int
            const bf16_t* w2, const bf16_t* xa, int xa_ld, const bf16_t* lb, int s0, int s1, const bf16_t* va,
            const bf16_t* vb, const bf16_t* resid, hipStream_t s, bool timed) {
     // kernel choice is a property of the phase, never of the packing (batch invariance)
-    const int kernel = e->phase_decode ? 0 : 1;
+    const int kernel = e->phase_decode ? 2 : 1;
     if (timed) {
         TimeScope t(e, e->phase_decode ? 1 : 0, s);
         return dh_linear_impl(x, w, y, M, N, K, epi, w2, xa, xa_ld, lb, e->d.lora_scale, s0, s1, va, vb, resid, kernel, s);
@@ -126,7 +129,7 @@ int run_layers(dh_engine* e, const int64_t* ids, int n_tok, int n_seq, int max_q
     e->phase_decode = decode;
     const dh_model_desc& D = e->d;
     const int d = D.n_embd, I = D.intermediate, hs = D.head_size, H = D.n_head, G = D.n_groups;
-    int32_t* seq_slot = e->seq_meta;
+    int32_t* seq_slot = e->seq_meta + e->slot_base;      // identity: sequence i of the call lives in slot base+i
     int32_t* q_start = e->seq_meta + e->max_batch;
     int32_t* q_len = e->seq_meta + 2 * e->max_batch;
     int32_t* kv_pos0 = e->seq_meta + 3 * e->max_batch;   // decode: kv_len
@@ -185,13 +188,13 @@ int pick_ksplit(int tiles, int nks) {
     return ks;
 }
 
-// Single-token step for n_seq <= 32 sequences: 7 launches per layer (decode_fused.hip).  Leaves
+// Single-token step for n_seq <= MAX_DECODE_ROWS sequences: 7 launches per layer (decode_fused.hip).  Leaves
 // ln_f(x) in e->xn.  kv_len lives in seq_meta[3B..], seq_slot in seq_meta[0..].
 int run_layers_decode(dh_engine* e, const int64_t* ids, int n_seq, const uint8_t* tail_flags, hipStream_t s) {
     const dh_model_desc& D = e->d;
     const int d = D.n_embd, I = D.intermediate, hs = D.head_size, H = D.n_head, G = D.n_groups;
     const uint8_t* rt = e->rsqrt_vec > 0 ? tail_flags : nullptr;
-    const int32_t* seq_slot = e->seq_meta;
+    const int32_t* seq_slot = e->seq_meta + e->slot_base;
     const int32_t* kv_len = e->seq_meta + 3 * e->max_batch;
     e->phase_decode = true;
     int rc;
@@ -281,7 +284,7 @@ extern "C" int dh_engine_create(const dh_model_desc* desc, int max_batch, int s_
     rc |= dmalloc(e, &e->last_row, (size_t)max_batch);
     rc |= dmalloc(e, &e->step_dev, 1);
     rc |= dmalloc(e, &e->dec_ids, (size_t)max_batch);
-    rc |= dmalloc(e, &e->part32, (size_t)16 * 32 * (e->qkv_dim + 48));
+    rc |= dmalloc(e, &e->part32, (size_t)16 * (max_batch < 32 ? 32 : (max_batch < MAX_DECODE_ROWS ? max_batch : MAX_DECODE_ROWS)) * (e->qkv_dim + 48));
     rc |= dmalloc(e, &e->row_tail, T);
     rc |= dmalloc(e, &e->last_tail, (size_t)max_batch);
     rc |= dmalloc(e, &e->ones, (size_t)max_batch);
@@ -345,8 +348,15 @@ extern "C" int dh_engine_read(dh_engine* e, int what, int layer, void* dst, int6
 
 extern "C" int dh_engine_forward(dh_engine* e, const int64_t* ids, const int32_t* h_seq_len, const int32_t* h_pos0,
                                  int n_seq, dh_bf16* logits_all, dh_bf16* logits_last, void* stream) {
+    return dh_engine_forward_at(e, ids, h_seq_len, h_pos0, n_seq, 0, logits_all, logits_last, stream);
+}
+
+extern "C" int dh_engine_forward_at(dh_engine* e, const int64_t* ids, const int32_t* h_seq_len, const int32_t* h_pos0,
+                                    int n_seq, int slot_base, dh_bf16* logits_all, dh_bf16* logits_last, void* stream) {
     DH_CHECK(e && ids && h_seq_len && h_pos0, "dh_engine_forward: null argument");
-    DH_CHECK(n_seq > 0 && n_seq <= e->max_batch, "dh_engine_forward: n_seq=%d exceeds max_batch=%d", n_seq, e->max_batch);
+    DH_CHECK(n_seq > 0 && slot_base >= 0 && slot_base + n_seq <= e->max_batch,
+             "dh_engine_forward: sequences [%d, %d) exceed max_batch=%d", slot_base, slot_base + n_seq, e->max_batch);
+    e->slot_base = slot_base;
     hipStream_t s = (hipStream_t)stream;
     int n_tok = 0, max_q = 0;
     for (int i = 0; i < n_seq; ++i) {
@@ -368,7 +378,7 @@ extern "C" int dh_engine_forward(dh_engine* e, const int64_t* ids, const int32_t
         h_meta[B + i] = t;
         h_meta[2 * B + i] = h_seq_len[i];
         h_meta[3 * B + i] = max_q == 1 ? h_pos0[i] + 1 : h_pos0[i];   // single-token call: kv_len
-        for (int j = 0; j < h_seq_len[i]; ++j, ++t) { h_slot[t] = i; h_pos[t] = h_pos0[i] + j; }
+        for (int j = 0; j < h_seq_len[i]; ++j, ++t) { h_slot[t] = slot_base + i; h_pos[t] = h_pos0[i] + j; }
         h_meta[4 * B + i] = t - 1;
     }
     // Q11: rows torch's CPU bf16 rsqrt would process in its scalar tail loop
@@ -393,7 +403,7 @@ extern "C" int dh_engine_forward(dh_engine* e, const int64_t* ids, const int32_t
     DH_HIP(hipEventRecord(e->ev_stage, s));
     int rc;
     // one token per sequence == a decode step (what generate()'s loop issues): same kernels as dh_engine_decode
-    const bool fast = max_q == 1 && n_seq <= 32 && e->d.n_embd % 16 == 0;
+    const bool fast = max_q == 1 && n_seq <= MAX_DECODE_ROWS && e->d.n_embd % 16 == 0;
     if (fast) {
         if ((rc = run_layers_decode(e, ids, n_seq, e->row_tail, s))) return rc;
         e->last_ntok = n_tok;
@@ -429,7 +439,7 @@ int decode_step(dh_engine* e, int64_t* tokens, int tok_ld, int32_t* length, int3
                        e->tok_slot, e->tok_pos, kv_len, e->step_dev, n_seq, e->s_max);
     DH_LAUNCH_CHECK();
     int rc;
-    if (n_seq <= 32) {
+    if (n_seq <= MAX_DECODE_ROWS) {
         if ((rc = run_layers_decode(e, e->dec_ids, n_seq, e->ones, s))) return rc;
         if ((rc = head_normed(e, n_seq, e->logits, s))) return rc;
     } else {
@@ -450,6 +460,7 @@ extern "C" int dh_engine_decode(dh_engine* e, int64_t* tokens, int tok_ld, int32
     DH_CHECK(n_seq > 0 && n_seq <= e->max_batch, "dh_engine_decode: n_seq=%d exceeds max_batch=%d", n_seq, e->max_batch);
     DH_CHECK(temperature > 0.f && top_k >= 0, "dh_engine_decode: bad sampling parameters");
     if (n_steps <= 0) return 0;
+    e->slot_base = 0;
     hipStream_t s = (hipStream_t)stream;
     // seq_slot (seq_meta[0..B)) is the identity from engine creation on; nothing here touches the host
     // staging buffer, so the call never waits for the stream (several engines can be driven back to back)

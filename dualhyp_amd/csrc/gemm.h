@@ -23,12 +23,17 @@ struct GemmArgs {
 // M <= 32: one pass over W straight from HBM to registers (gemm_skinny.hip)
 int dh_linear_skinny(const GemmArgs& a, int epilogue, hipStream_t s);
 
+// decode phase, M <= 256 rows from several batches in one launch (gemm_mid.hip)
+bool dh_linear_mid_ok(const GemmArgs& a, int epilogue);
+int dh_linear_mid(const GemmArgs& a, int epilogue, hipStream_t s);
+extern int g_mid;            // 1: the decode phase uses the LDS-staged-x streaming kernel for PLAIN/SWIGLU/ADAPTER
+
 // M >= 256: 256 x 256 x 64 tiles, one block per CU (gemm256.hip)
 int dh_linear_256(GemmArgs a, int epilogue, hipStream_t s);
 extern int g_gemm_variant;   // 1: use the 256-tile kernel when the shape allows, 0: always 128-tile
 
-// dh_linear_bf16 with an explicit kernel choice.  kernel: 0 = by shape (M <= 32 -> skinny),
-// 1 = tiled MFMA kernel whatever M.  The engine pins the choice per PHASE (prefill = tiled,
+// dh_linear_bf16 with an explicit kernel choice.  kernel: 0 = by shape (M <= 32 -> streaming),
+// 1 = tiled MFMA kernel whatever M, 2 = decode phase (streaming kernels up to 256 rows).  The engine pins the choice per PHASE (prefill = tiled,
 // single-token decode = skinny) so a sequence's result never depends on how many other
 // sequences were packed into the same call (fp32 summation order differs between the two).
 int dh_linear_impl(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N, int K, int epilogue,

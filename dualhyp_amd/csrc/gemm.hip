@@ -238,7 +238,10 @@ int dh_linear_impl(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N,
     a.lora_scale = lora_scale;
     a.nb_m = cdiv(M, BT);
     a.nb_n = (epilogue == DH_EPI_SWIGLU) ? cdiv(N, 64) : cdiv(N, BT);
-    const bool skinny = kernel == 0 && M <= 32 && K % 32 == 0;   // weight-streaming kernel (gemm_skinny.hip)
+    if ((kernel == 2 || (kernel == 0 && M <= 32)) && (epilogue != DH_EPI_SWIGLU || (w2 != nullptr && resid == nullptr)) &&
+        (epilogue != DH_EPI_ADAPTER || (vec_a && vec_b)) && dh_linear_mid_ok(a, epilogue))
+        return dh_linear_mid(a, epilogue, s);
+    const bool skinny = (kernel == 0 || kernel == 2) && M <= 32 && K % 32 == 0;   // weight-streaming kernel (gemm_skinny.hip)
     const bool big = !skinny && g_gemm_variant >= 1 && M >= 256 && N >= (epilogue == DH_EPI_SWIGLU ? 128 : 256);
     if (big) {
         if (epilogue == DH_EPI_LORA) {

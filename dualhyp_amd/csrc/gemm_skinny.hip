@@ -213,8 +213,8 @@ int g_swiglu2 = 1;
 __global__ __launch_bounds__(512, 2) void gemm_skinny_partial_kernel(const bf16_t* __restrict__ x,
                                                                    const bf16_t* __restrict__ w,
                                                                    const bf16_t* __restrict__ w_ext,
-                                                                   float* __restrict__ y32, int M, int n_main,
-                                                                   int N, int K) {
+                                                                   float* __restrict__ y32, int M, int m_total,
+                                                                   int n_main, int N, int K) {
     __shared__ __attribute__((aligned(16))) float part[NW][32][ROWS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * ROWS, ksplit = gridDim.y;
@@ -258,25 +258,27 @@ __global__ __launch_bounds__(512, 2) void gemm_skinny_partial_kernel(const bf16_
     float s = 0.f;
 #pragma unroll
     for (int wv = 0; wv < NW; ++wv) s += p[wv * 32 * ROWS];
-    y32[((size_t)blockIdx.y * M + tm) * N + nn] = s;
+    y32[((size_t)blockIdx.y * m_total + tm) * N + nn] = s;   // [ksplit][m_total][N], this launch's rows at y32
 }
 
 // Row-parallel variant: the 8 waves of a block own 16 W rows EACH (128 rows per block) and all
-// work on the SAME K-slice, so the x slice [32 x 32*KPS] is staged once per block in LDS (x is
+// work on the SAME K-slice, so the x slice [32*NG x 32*KPS] is staged once per block in LDS (x is
 // 2/3 of the load instructions when every wave fetches its own fragments) and no cross-wave
-// reduction is needed: each wave stores its fp32 tile straight from the accumulators.
-//   grid (ceil(N/128), ksplit), K-slice = KPS k-steps of 32.
-template <int KPS>
-__global__ __launch_bounds__(512, 2) void gemm_skinny_rows_kernel(const bf16_t* __restrict__ x,
-                                                                const bf16_t* __restrict__ w,
-                                                                const bf16_t* __restrict__ w_ext,
-                                                                float* __restrict__ y32, int M, int n_main, int N,
-                                                                int K) {
+// reduction is needed: each wave stores its fp32 tile straight from the accumulators.  NG 32-row
+// groups of x (several batches decoded in one launch) reuse the W fragments held in registers.
+//   grid (ceil(N/128), ksplit, ceil(M / (32*NG))), K-slice = KPS k-steps of 32.
+template <int KPS, int NG>
+__global__ __launch_bounds__(512, NG == 1 ? 2 : 1) void gemm_skinny_rows_kernel(const bf16_t* __restrict__ x,
+                                                                              const bf16_t* __restrict__ w,
+                                                                              const bf16_t* __restrict__ w_ext,
+                                                                              float* __restrict__ y32, int M, int n_main,
+                                                                              int N, int K) {
     constexpr int XS = KPS * 64 + 16;                      // padded row stride of the x slice (bytes)
-    __shared__ __attribute__((aligned(16))) char sx[32 * XS];
+    extern __shared__ __attribute__((aligned(16))) char sx[];   // [NG*32][XS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, kg = lane >> 4;
     const int n0 = blockIdx.x * 128 + wave * 16;
+    const int m0 = blockIdx.z * (NG * 32);
     const int nks = K / 32;
     const int ks_begin = blockIdx.y * KPS;
     const int ks_cnt = min(KPS, nks - ks_begin);          // >= 1 by construction of the grid
@@ -287,32 +289,63 @@ __global__ __launch_bounds__(512, 2) void gemm_skinny_rows_kernel(const bf16_t* 
 #pragma unroll
     for (int c = 0; c < KPS; ++c)
         if (c < ks_cnt) wf[c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wrow + c * 32));
-    // stage the x slice: 32 rows x ks_cnt*4 chunks of 16 B
-    for (int c = tid; c < 32 * KPS * 4; c += 512) {
+    // stage the x slice: 32*NG rows x ks_cnt*4 chunks of 16 B
+#pragma unroll
+    for (int i = 0; i < NG * 32 * KPS * 4 / 512; ++i) {
+        const int c = tid + i * 512;
         const int row = c / (KPS * 4), col = c % (KPS * 4);
         if (col < ks_cnt * 4) {
-            const int m = row < M ? row : M - 1;
+            int m = m0 + row;
+            m = m < M ? m : M - 1;
             *reinterpret_cast<uint4*>(sx + row * XS + col * 16) =
                 *reinterpret_cast<const uint4*>(x + (size_t)m * K + ks_begin * 32 + col * 8);
         }
     }
     __syncthreads();
-    f32x4 acc_lo = {0.f, 0.f, 0.f, 0.f}, acc_hi = {0.f, 0.f, 0.f, 0.f};
+    const int nn = n0 + kg * 4;
 #pragma unroll
-    for (int c = 0; c < KPS; ++c) {
-        if (c < ks_cnt) {
-            const bf16x8 xl = *reinterpret_cast<const bf16x8*>(sx + lrow * XS + c * 64 + kg * 16);
-            const bf16x8 xh = *reinterpret_cast<const bf16x8*>(sx + (16 + lrow) * XS + c * 64 + kg * 16);
-            acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c], xl, acc_lo, 0, 0, 0);
-            acc_hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c], xh, acc_hi, 0, 0, 0);
+    for (int g = 0; g < NG; ++g) {
+        const int mg = m0 + g * 32;
+        if (mg >= M) break;
+        f32x4 acc_lo = {0.f, 0.f, 0.f, 0.f}, acc_hi = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < KPS; ++c) {
+            if (c < ks_cnt) {
+                const bf16x8 xl = *reinterpret_cast<const bf16x8*>(sx + (g * 32 + lrow) * XS + c * 64 + kg * 16);
+                const bf16x8 xh = *reinterpret_cast<const bf16x8*>(sx + (g * 32 + 16 + lrow) * XS + c * 64 + kg * 16);
+                acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c], xl, acc_lo, 0, 0, 0);
+                acc_hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c], xh, acc_hi, 0, 0, 0);
+            }
+        }
+        if (nn < N) {
+            float* out = y32 + (size_t)blockIdx.y * M * N + nn;
+            if (mg + lrow < M) *reinterpret_cast<f32x4*>(out + (size_t)(mg + lrow) * N) = acc_lo;
+            if (mg + 16 + lrow < M) *reinterpret_cast<f32x4*>(out + (size_t)(mg + 16 + lrow) * N) = acc_hi;
         }
     }
-    const int nn = n0 + kg * 4;
-    if (nn < N) {
-        float* out = y32 + (size_t)blockIdx.y * M * N + nn;
-        if (lrow < M) *reinterpret_cast<f32x4*>(out + (size_t)lrow * N) = acc_lo;
-        if (16 + lrow < M) *reinterpret_cast<f32x4*>(out + (size_t)(16 + lrow) * N) = acc_hi;
+}
+
+template <int KPS, int NG>
+int launch_rows(const bf16_t* x, const bf16_t* w, const bf16_t* w_ext, float* y32, int M, int n_main, int N, int K,
+                int ksplit, hipStream_t s) {
+    constexpr int lds = NG * 32 * (KPS * 64 + 16);
+    static bool attr = false;
+    if (!attr && lds > 48 * 1024) {
+        DH_HIP(hipFuncSetAttribute((const void*)gemm_skinny_rows_kernel<KPS, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr = true;
     }
+    dim3 grid((N + 127) / 128, ksplit, cdiv(M, NG * 32)), block(512);
+    hipLaunchKernelGGL((gemm_skinny_rows_kernel<KPS, NG>), grid, block, lds, s, x, w, w_ext, y32, M, n_main, N, K);
+    DH_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int KPS>
+int launch_rows_ng(const bf16_t* x, const bf16_t* w, const bf16_t* w_ext, float* y32, int M, int n_main, int N, int K,
+                   int ksplit, hipStream_t s) {
+    if (M <= 32) return launch_rows<KPS, 1>(x, w, w_ext, y32, M, n_main, N, K, ksplit, s);
+    if (M <= 64) return launch_rows<KPS, 2>(x, w, w_ext, y32, M, n_main, N, K, ksplit, s);
+    return launch_rows<KPS, 4>(x, w, w_ext, y32, M, n_main, N, K, ksplit, s);
 }
 
 int g_skinny_variant = 1;   // 0: K split over the waves of a block, 1: row-parallel with LDS-staged x
@@ -332,7 +365,7 @@ int launch(const GemmArgs& a, hipStream_t s) {
 
 extern "C" int dh_linear_partial_bf16(const dh_bf16* x, const dh_bf16* w, const dh_bf16* w_ext, float* y32, int M,
                                       int n_main, int n_ext, int K, int ksplit, void* stream) {
-    DH_CHECK(x && w && y32 && M >= 1 && M <= 32, "dh_linear_partial_bf16: need 1 <= M <= 32 (got %d)", M);
+    DH_CHECK(x && w && y32 && M >= 1 && M <= 256, "dh_linear_partial_bf16: need 1 <= M <= 256 (got %d)", M);
     DH_CHECK(K % 32 == 0 && n_main % ROWS == 0 && n_ext % ROWS == 0 && n_main > 0 && n_ext >= 0,
              "dh_linear_partial_bf16: K %% 32 and row counts %% 16 must be 0");
     DH_CHECK(n_ext == 0 || w_ext, "dh_linear_partial_bf16: null w_ext");
@@ -340,18 +373,18 @@ extern "C" int dh_linear_partial_bf16(const dh_bf16* x, const dh_bf16* w, const 
     const int N = n_main + n_ext;
     const int nks = K / 32;
     const int kps = (nks + ksplit - 1) / ksplit;
+    hipStream_t s = (hipStream_t)stream;
+    // the kernel is a function of (K, ksplit) alone, never of M: rows of a larger call equal the same rows alone
     if (g_skinny_variant == 1 && (kps == 8 || kps == 16) && (ksplit - 1) * kps < nks && N % 4 == 0) {
-        dim3 grid((N + 127) / 128, ksplit), block(512);
-        if (kps == 8)
-            hipLaunchKernelGGL((gemm_skinny_rows_kernel<8>), grid, block, 0, (hipStream_t)stream, x, w, w_ext ? w_ext : w,
-                               y32, M, n_main, N, K);
-        else
-            hipLaunchKernelGGL((gemm_skinny_rows_kernel<16>), grid, block, 0, (hipStream_t)stream, x, w, w_ext ? w_ext : w,
-                               y32, M, n_main, N, K);
-    } else {
-        DH_CHECK(ksplit <= 8, "dh_linear_partial_bf16: ksplit must be 1..8 for this shape");
-        hipLaunchKernelGGL(gemm_skinny_partial_kernel, dim3(N / ROWS, ksplit), dim3(512), 0, (hipStream_t)stream, x, w,
-                           w_ext ? w_ext : w, y32, M, n_main, N, K);
+        if (kps == 8) return launch_rows_ng<8>(x, w, w_ext ? w_ext : w, y32, M, n_main, N, K, ksplit, s);
+        return launch_rows_ng<16>(x, w, w_ext ? w_ext : w, y32, M, n_main, N, K, ksplit, s);
+    }
+    DH_CHECK(ksplit <= 8, "dh_linear_partial_bf16: ksplit must be 1..8 for this shape");
+    // K-split-over-waves kernel: 32 rows per launch
+    for (int m0 = 0; m0 < M; m0 += 32) {
+        const int mm = M - m0 < 32 ? M - m0 : 32;
+        hipLaunchKernelGGL(gemm_skinny_partial_kernel, dim3(N / ROWS, ksplit), dim3(512), 0, s, x + (size_t)m0 * K, w,
+                           w_ext ? w_ext : w, y32 + (size_t)m0 * N, mm, M, n_main, N, K);
     }
     DH_LAUNCH_CHECK();
     return 0;
@@ -361,6 +394,7 @@ extern "C" int dh_set_tuning(int key, int value) {
     if (key == 0) { g_skinny_variant = value; return 0; }
     if (key == 1) { g_gemm_variant = value; return 0; }
     if (key == 2) { g_swiglu2 = value; return 0; }
+    if (key == 3) { g_mid = value; return 0; }
     dh_set_error("dh_set_tuning: unknown key %d", key);
     return 1;
 }

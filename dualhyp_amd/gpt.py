@@ -341,7 +341,7 @@ class _Engine:
             pass
 
     def forward(self, ids: torch.Tensor, seq_len: List[int], pos0: List[int], want_all: bool,
-                want_last: bool) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+                want_last: bool, slot_base: int = 0) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
         n = len(seq_len)
         n_tok = int(sum(seq_len))
         ids = ids.reshape(-1)
@@ -352,8 +352,8 @@ class _Engine:
         a_len = (C.c_int32 * n)(*seq_len)
         a_pos = (C.c_int32 * n)(*pos0)
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.dh_engine_forward(self.handle, ids.data_ptr(), a_len, a_pos, n, ops._p(la), ops._p(ll),
-                                                  torch.cuda.current_stream().cuda_stream))
+            _lib.check(self.lib.dh_engine_forward_at(self.handle, ids.data_ptr(), a_len, a_pos, n, int(slot_base),
+                                                     ops._p(la), ops._p(ll), torch.cuda.current_stream().cuda_stream))
         return la, ll
 
     def decode(self, tokens: torch.Tensor, length: torch.Tensor, done: torch.Tensor, n_steps: int, temperature: float,

@@ -60,17 +60,6 @@ class BatchPipeline:
                 generate_batch(m, prompts, max_new_tokens, **kw)
         torch.cuda.synchronize(self.device)
 
-    def run_gangs(self, batches: Sequence[Sequence[torch.Tensor]], max_new_tokens: int, **kw: Any) -> List[List[torch.Tensor]]:
-        """Process `batches` in gangs of n_engines: prefills exclusive, decode loops concurrent
-        (generate_gang).  Single host thread, no Python-side concurrency needed."""
-        from .generate import generate_gang
-        out: List[List[torch.Tensor]] = []
-        E = len(self.models)
-        with torch.cuda.device(self.device):
-            for g in range(0, len(batches), E):
-                out += generate_gang(self.models, batches[g:g + E], max_new_tokens, streams=self.streams, **kw)
-        return out
-
     def submit(self, prompts: Sequence[torch.Tensor], max_new_tokens: int, **kw: Any) -> "Future[List[torch.Tensor]]":
         """Queue one batch; the future resolves to generate_batch's result."""
         return self._pool.submit(self._run, prompts, max_new_tokens, kw)

@@ -93,7 +93,7 @@ int dh_linear_bf16(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N,
                    const dh_bf16* vec_a, const dh_bf16* vec_b, const dh_bf16* resid,
                    void* stream);
 
-/* fp32 partial sums for the fused decode consumers below (M <= 32, weight streaming):
+/* fp32 partial sums for the fused decode consumers below (M <= 256, weight streaming):
  *   y32[p][m][n] = sum over K-slice p of x[m,:] . W'[n,:],  W' = [w (n_main rows) ; w_ext (n_ext rows)]
  * y32: [ksplit][M][n_main+n_ext] fp32.  w_ext is the rank-padded LoRA A (so x·A^T comes out of the
  * same pass over x as x·W^T and never needs its own launch).  K %% 32 == 0, rows %% 16 == 0. */
@@ -248,6 +248,12 @@ int64_t dh_engine_device_bytes(const dh_engine* e);
 int dh_engine_forward(dh_engine* e, const int64_t* ids, const int32_t* h_seq_len,
                       const int32_t* h_pos0, int n_seq, dh_bf16* logits_all,
                       dh_bf16* logits_last, void* stream);
+/* Same, with sequence i of the call living in KV-cache slot slot_base + i: several batches are
+ * prefilled one after the other into one engine and then decoded together (dh_engine_decode over
+ * all occupied slots; rows of a larger decode call equal the same rows decoded alone). */
+int dh_engine_forward_at(dh_engine* e, const int64_t* ids, const int32_t* h_seq_len,
+                         const int32_t* h_pos0, int n_seq, int slot_base, dh_bf16* logits_all,
+                         dh_bf16* logits_last, void* stream);
 
 /* Reproduce the rsqrt rounding of the reference's CPU path (see dh_rmsnorm_bf16 row_tail):
  * vec_width = lanes of torch's bf16 vector loop on the reference host (32 on AVX-512, 16 on

@@ -170,7 +170,28 @@ def test_block_intermediates(golden):
         act = ops.linear(n2r, blk.mlp.fc_1.linear.weight, epilogue=ops.EPI_SWIGLU, w2=blk.mlp.fc_2.linear.weight)
         chk(act, "mlp_act", max_ulp=2, frac=0.003)
         out = blk.mlp(n2r, resid=x1r)
-        chk(out, "block_out", max_ulp=2, frac=0.003)
+        chk(out, "block_out", max_ulp=2, frac=0.005)   # K = 5632 fp32 chain order vs torch's: rounding-boundary flips
+
+
+@pytest.mark.parametrize("name", TINY)
+def test_joint_decode_is_batch_invariant(golden, name):
+    """More prompts than `prefill_batch`: chunked prefill into consecutive KV slots + ONE decode loop over
+    all rows (up to 256 rows take the streaming kernels).  Every row equals the same prompt generated in
+    a small batch / alone: the kernels' per-row summation order does not depend on the packing."""
+    t, meta = golden(name)
+    cfg, m = build(meta)
+    V = cfg.padded_vocab_size
+    g = torch.Generator().manual_seed(7)
+    prompts = [torch.randint(3, V, (int(n),), generator=g).to(DEV) for n in torch.randint(5, 40, (70,), generator=g)]
+    G = 9
+    joint = [o.cpu() for o in generate_batch(m, prompts, G, temperature=0.2, top_k=1, prefill_batch=16)]
+    assert len(joint) == 70
+    for a in range(0, 70, 16):
+        part = [o.cpu() for o in generate_batch(m, prompts[a:a + 16], G, temperature=0.2, top_k=1)]
+        for i, o in enumerate(part):
+            assert torch.equal(o, joint[a + i]), f"row {a + i} differs between the 70-row and the 16-row decode"
+    alone = generate(m, prompts[37], prompts[37].numel() + G, temperature=0.2, top_k=1).cpu()
+    assert torch.equal(alone, joint[37])
 
 
 def test_full_tinyllama_vs_reference(golden):
@@ -205,3 +226,13 @@ def test_full_tinyllama_vs_reference(golden):
     safe = G if (margins >= SAFE_MARGIN_ULPS).all() else int((margins < SAFE_MARGIN_ULPS).nonzero()[0])
     free = generate(m, t["idx"].to(DEV), T + G, temperature=0.2, top_k=1).cpu()
     assert torch.equal(free[: T + safe], ids[: T + safe])
+    # joint decode of 70 rows at full size (chunked prefill, streaming kernels with 4 row groups):
+    # the golden prompt rides in row 40 and must come out exactly as alone
+    g = torch.Generator().manual_seed(11)
+    V = cfg.padded_vocab_size
+    prompts = [torch.randint(3, V, (int(n),), generator=g).to(DEV) for n in torch.randint(8, 48, (70,), generator=g)]
+    prompts[40] = t["idx"].to(DEV)
+    joint = generate_batch(m, prompts, G, temperature=0.2, top_k=1, prefill_batch=32)
+    assert torch.equal(joint[40].cpu(), free)
+    small = generate_batch(m, prompts[32:64], G, temperature=0.2, top_k=1)
+    assert all(torch.equal(a, b) for a, b in zip(small, joint[32:64]))

@@ -153,6 +153,25 @@ def test_linear_decode_shapes(dev, M, d, I, r):
     check_ulp(got, sc * (F.linear(x, W) + bi), 2, 0.01, "decode adapter")
 
 
+@pytest.mark.parametrize("M", [33, 100, 256])
+@pytest.mark.parametrize("N,n_ext,K,ks", [(2560, 48, 2048, 8), (2048, 0, 5632, 11), (384, 16, 256, 1), (256, 16, 384, 2)])
+def test_linear_partial_wide_rows(dev, M, N, n_ext, K, ks):
+    """Several 32-row groups in one launch (joint decode of several batches): every group's partial
+    sums are bit-identical to the same rows in a launch of their own."""
+    from dualhyp_amd import ops
+    x = U((M, K), 1.0, f"wx{M}{K}").to(dev)
+    W = U((N, K), 0.05, f"ww{N}{K}").to(dev)
+    A = U((n_ext, K), 0.05, f"wa{K}").to(dev) if n_ext else None
+    wide = ops.linear_partial(x, W, A, ksplit=ks)
+    assert wide.shape == (ks, M, N + n_ext)
+    for m0 in range(0, M, 32):
+        alone = ops.linear_partial(x[m0:m0 + 32].contiguous(), W, A, ksplit=ks)
+        assert torch.equal(alone, wide[:, m0:m0 + 32]), f"rows {m0}.. differ"
+    ref = x.float() @ torch.cat([W, A]).float().T if n_ext else x.float() @ W.float().T
+    got = wide.sum(0)
+    assert (got - ref).abs().max().item() <= 1e-3 * ref.abs().max().item() + 1e-4
+
+
 def _attn_setup(dev, hs, n_head, n_groups, lens, pos0, s_max, seed):
     """Random qkv for a ragged batch -> (ops outputs, oracle-side q/k/v per sequence)."""
     from dualhyp_amd import ops
