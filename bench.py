@@ -53,7 +53,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--in-flight", type=int, default=4,
+    ap.add_argument("--in-flight", type=int, default=8,
                     help="batches (steps) decoded together per GPU: each batch of --batch prompts is prefilled on its "
                          "own, then the decode loop runs over all in-flight sequences at once")
     ap.add_argument("--schedule", choices=("merged", "threads"), default="merged",

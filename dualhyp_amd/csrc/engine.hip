@@ -45,8 +45,11 @@ struct dh_engine {
     // decode graph
     hipStream_t gstream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_stage = nullptr;
-    hipGraphExec_t gexec = nullptr;
-    struct { int64_t* tokens; int tok_ld; int32_t *length, *done; int n_seq, top_k; float temp; int64_t eos; uint64_t seed; } gkey{};
+    // captured decode steps, keyed by everything baked into the graph (a few batch sizes alternate in practice)
+    struct GKey { int64_t* tokens; int tok_ld; int32_t *length, *done; int n_seq, top_k; float temp; int64_t eos; uint64_t seed; };
+    struct GEntry { GKey key; hipGraphExec_t exec; uint64_t used; };
+    std::vector<GEntry> graphs;
+    uint64_t graph_clock = 0;
     int last_ntok = 0;
     int slot_base = 0;         // first KV-cache slot of the sequences of the current forward call
     bool capturing = false;   // no event records inside a stream capture
@@ -309,7 +312,7 @@ extern "C" int dh_engine_create(const dh_model_desc* desc, int max_batch, int s_
 
 extern "C" void dh_engine_destroy(dh_engine* e) {
     if (!e) return;
-    if (e->gexec) hipGraphExecDestroy(e->gexec);
+    for (auto& g : e->graphs) hipGraphExecDestroy(g.exec);
     void* ptrs[] = {e->kc, e->vtc, e->x, e->xn, e->qkv, e->qrot, e->att, e->xa, e->act, e->xlast, e->logits,
                     e->tok_slot, e->tok_pos, e->seq_meta, e->last_row, e->step_dev, e->dec_ids, e->dec_work,
                     e->row_tail, e->last_tail, e->ones, e->part32};
@@ -466,14 +469,21 @@ extern "C" int dh_engine_decode(dh_engine* e, int64_t* tokens, int tok_ld, int32
     // staging buffer, so the call never waits for the stream (several engines can be driven back to back)
     hipLaunchKernelGGL(set_i32_kernel, dim3(1), dim3(1), 0, s, e->step_dev, (int32_t)first_step);
     DH_LAUNCH_CHECK();
-    const bool same = e->gexec && e->gkey.tokens == tokens && e->gkey.tok_ld == tok_ld && e->gkey.length == length &&
-                      e->gkey.done == done && e->gkey.n_seq == n_seq && e->gkey.top_k == top_k &&
-                      e->gkey.temp == temperature && e->gkey.eos == eos_id && e->gkey.seed == seed;
+    const dh_engine::GKey key{tokens, tok_ld, length, done, n_seq, top_k, temperature, eos_id, seed};
+    hipGraphExec_t gexec = nullptr;
+    for (auto& g : e->graphs) {
+        const dh_engine::GKey& k = g.key;
+        if (k.tokens == key.tokens && k.tok_ld == key.tok_ld && k.length == key.length && k.done == key.done &&
+            k.n_seq == key.n_seq && k.top_k == key.top_k && k.temp == key.temp && k.eos == key.eos && k.seed == key.seed) {
+            gexec = g.exec;
+            g.used = ++e->graph_clock;
+            break;
+        }
+    }
     // hand over from the caller's stream to the engine's capture-capable stream
     DH_HIP(hipEventRecord(e->ev_in, s));
     DH_HIP(hipStreamWaitEvent(e->gstream, e->ev_in, 0));
-    if (!same) {
-        if (e->gexec) { hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
+    if (!gexec) {
         hipGraph_t graph = nullptr;
         DH_HIP(hipStreamBeginCapture(e->gstream, hipStreamCaptureModeThreadLocal));
         e->capturing = true;
@@ -482,12 +492,20 @@ extern "C" int dh_engine_decode(dh_engine* e, int64_t* tokens, int tok_ld, int32
         hipError_t ce = hipStreamEndCapture(e->gstream, &graph);
         if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
         DH_CHECK(ce == hipSuccess && graph, "dh_engine_decode: graph capture failed: %s", hipGetErrorString(ce));
-        hipError_t ie = hipGraphInstantiate(&e->gexec, graph, nullptr, nullptr, 0);
+        hipError_t ie = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
         hipGraphDestroy(graph);
         DH_CHECK(ie == hipSuccess, "dh_engine_decode: hipGraphInstantiate failed: %s", hipGetErrorString(ie));
-        e->gkey = {tokens, tok_ld, length, done, n_seq, top_k, temperature, eos_id, seed};
+        if (e->graphs.size() >= 8) {   // evict the least recently used (its launches are stream-ordered before the destroy)
+            size_t lru = 0;
+            for (size_t i = 1; i < e->graphs.size(); ++i)
+                if (e->graphs[i].used < e->graphs[lru].used) lru = i;
+            DH_HIP(hipStreamSynchronize(e->gstream));
+            hipGraphExecDestroy(e->graphs[lru].exec);
+            e->graphs.erase(e->graphs.begin() + lru);
+        }
+        e->graphs.push_back({key, gexec, ++e->graph_clock});
     }
-    for (int i = 0; i < n_steps; ++i) DH_HIP(hipGraphLaunch(e->gexec, e->gstream));
+    for (int i = 0; i < n_steps; ++i) DH_HIP(hipGraphLaunch(gexec, e->gstream));
     DH_HIP(hipEventRecord(e->ev_out, e->gstream));
     DH_HIP(hipStreamWaitEvent(s, e->ev_out, 0));
     return 0;
