@@ -214,13 +214,14 @@ int launch(const GemmArgs& a, hipStream_t s) {
 }  // namespace
 
 int g_gemm_variant = 1;
+int g_linear_phase = 0;   // kernel choice of the public dh_linear_bf16 (dh_set_tuning key 4; tools and tests)
 
 extern "C" int dh_linear_bf16(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N, int K, int epilogue,
                               const dh_bf16* w2, const dh_bf16* xa, int xa_ld, const dh_bf16* lora_b,
                               float lora_scale, int split0, int split1, const dh_bf16* vec_a,
                               const dh_bf16* vec_b, const dh_bf16* resid, void* stream) {
     return dh_linear_impl(x, w, y, M, N, K, epilogue, w2, xa, xa_ld, lora_b, lora_scale, split0, split1, vec_a, vec_b,
-                          resid, 0, (hipStream_t)stream);
+                          resid, g_linear_phase, (hipStream_t)stream);
 }
 
 int dh_linear_impl(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N, int K, int epilogue,

@@ -1,12 +1,17 @@
 // y[M, N] = epilogue(x · W^T) for the decode step, M <= 256 rows (one 32-sequence batch, or several
-// batches sharing one launch: generate.py generate_gang).  HBM-bound weight streaming; x is staged
-// ONCE per block in LDS (double-buffered K-slices) and shared by the 8 waves instead of being fetched
-// per wave from L2 as gemm_skinny.hip does, W goes global -> VGPR three slices ahead.
-//   block : 512 threads = 8 waves = RS row sets x KQ K-parts; a wave owns 16 W rows (SWIGLU: of fc_1
-//           AND fc_2) and KSL/KQ of the 8 k-steps of every slice, so a block covers only 16*RS output
+// batches decoded jointly: generate.py generate_batch).  HBM-bound weight streaming; x is staged
+// ONCE per block in LDS and shared by the 8 waves instead of being fetched per wave from L2 as
+// gemm_skinny.hip does.
+//   block : 640 threads = 8 compute waves (RS row sets x KQ K-parts) + 2 loader waves; a compute wave owns 16 W rows (SWIGLU: of fc_1
+//           AND fc_2) and KSL/KQ of the 4 k-steps of every slice, so a block covers only 16*RS output
 //           columns and even N = 5632 puts 176 blocks on the chip (SWIGLU: RS 2 x KQ 4, else 4 x 2)
-//   W     : ring of PD+1 slice fragments per wave, 12 KiB in flight per wave (96 KiB per block)
-//   x     : rows [m0, m0 + 32*NG) of the slice in LDS, 528-B padded rows
+//   W     : global -> VGPR, ring of 8 slices per wave: 14 KiB in flight per wave, 112 KiB per block
+//           (6 slices for SWIGLU with 4 row groups: the register budget at 10 waves is 170 VGPRs)
+//   x     : rows [m0, m0 + 32*NG) x 128 k per slice, global -> LDS directly (global_load_lds, 16 B per
+//           lane) by the two loader waves, 4 buffers, requested 3 slices ahead; 256-B rows, 16-B chunk
+//           index XOR (row & 15) applied on the SOURCE address so the fragment reads are conflict free
+//   sync  : one s_barrier per slice; only the loader waves wait on a counted s_waitcnt (vmcnt is an
+//           in-order counter: x requests issued by a compute wave would drain its W queue every slice)
 //   MFMA  : v_mfma_f32_16x16x32_bf16, C^T[16 n][16 m] += W[16 n][32 k] · x[16 m][32 k]^T
 //   reduce: the KQ partial accumulators meet in LDS (the x buffers are free by then), summed in
 //           K-part order by the first wave of each row set, which also runs the epilogue
@@ -19,10 +24,10 @@
 
 namespace {
 
-constexpr int KSL = 8;             // k-steps per slice
-constexpr int XS = KSL * 64 + 16;  // padded LDS row stride (bytes)
-constexpr int PD = 3;              // W slices requested ahead of the MFMAs
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // (arrays of HIP's uint4 struct are not promoted to registers)
+constexpr int KSL = 4;             // k-steps (of 32) per slice
+constexpr int XROW = KSL * 64;     // LDS row: 256 B = 16 chunks of 16 B
+constexpr int NBUF = 4;            // x slices resident in LDS
+constexpr int XD = 3;              // x slices requested ahead
 
 template <int EPI>
 struct MidShape {
@@ -32,101 +37,109 @@ struct MidShape {
     static constexpr int RS = 8 / KQ;          // 16-row sets per block
     static constexpr int KPW = KSL / KQ;       // k-steps per wave per slice
 };
+// W slices held per wave (RING-1 in flight + the one being multiplied); 170 VGPRs per wave at 10 waves
+template <int EPI, int NG> constexpr int mid_ring() { return (EPI == DH_EPI_SWIGLU && NG == 4) ? 6 : 8; }
 
 template <int EPI, int NG>
-__global__ __launch_bounds__(512) void gemm_mid_kernel(GemmArgs a) {
+__global__ __launch_bounds__(640) void gemm_mid_kernel(GemmArgs a) {
     using S = MidShape<EPI>;
     constexpr bool SW = S::SW;
-    constexpr int NM = S::NM, KQ = S::KQ, RS = S::RS, KPW = S::KPW, RING = PD + 1;
-    constexpr int CPT = NG * 32 * KSL * 4 / 512;          // 16-B x chunks per thread per slice
+    constexpr int NM = S::NM, KQ = S::KQ, RS = S::RS, KPW = S::KPW;
+    constexpr int RING = mid_ring<EPI, NG>(), PD = RING - 1;
     constexpr int NI = NG * NM * 2;                       // accumulator tiles per wave
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][NG*32][XS]
+    constexpr int NXL = NG * 4;                           // x requests per loader wave per slice (4 rows each)
+    constexpr int XBUF = NG * 32 * XROW;                  // bytes per x buffer
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [NBUF][NG*32][XROW]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * (NG * 32);
+    const int nsl = a.K / (KSL * 32);                     // K % 128 == 0 (checked on the host)
+
+    if (wave >= 8) {
+        // ---- loader waves: x slices global -> LDS, XD slices ahead of the MFMAs.  vmcnt is an in-order
+        // counter per wave: issued by the compute waves, these requests would force their deep W queue
+        // to drain at every slice.  Request j covers rows 4j..4j+3; lane -> (row 4j + lane/16, chunk lane%16).
+        const int ldr = wave - 8;
+        const bf16_t* xsrc[NXL];
+#pragma unroll
+        for (int i = 0; i < NXL; ++i) {
+            const int row = 4 * (ldr + 2 * i) + (lane >> 4);
+            int m = m0 + row;
+            m = m < a.M ? m : a.M - 1;
+            xsrc[i] = a.x + (size_t)m * a.K + ((lane & 15) ^ (row & 15)) * 8;
+        }
+        auto load_x = [&](int s) __attribute__((always_inline)) {
+            const int ko = s < nsl ? s * (KSL * 32) : 0;       // past K: L2 hits that keep the count uniform
+            char* xb = smem + (s % NBUF) * XBUF;
+#pragma unroll
+            for (int i = 0; i < NXL; ++i) glds16(xsrc[i] + ko, xb + (ldr + 2 * i) * (4 * XROW));
+        };
+#pragma unroll
+        for (int p = 0; p < XD; ++p) load_x(p);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((XD - 1) * NXL) : "memory");   // slice 0 has landed
+        __builtin_amdgcn_s_barrier();
+        for (int s = 0; s < nsl; ++s) {
+            load_x(s + XD);            // buffer (s+XD) % NBUF was last read in step s-1, which ended with a barrier
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((XD - 1) * NXL) : "memory");   // slice s+1 has landed
+            __builtin_amdgcn_s_barrier();
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail requests still target LDS
+        __builtin_amdgcn_s_barrier();                       // x buffers free for the reduction
+        __builtin_amdgcn_s_barrier();                       // partial tiles written (compute waves)
+        return;
+    }
+
     const int lrow = lane & 15, kg = lane >> 4;
     const int rs = wave % RS, kq = wave / RS;
     const int n0 = blockIdx.x * (16 * RS) + rs * 16;
-    const int m0 = blockIdx.y * (NG * 32);
     int n = n0 + lrow;
     n = n < a.N ? n : a.N - 1;
     const bf16_t* w1 = a.w + (size_t)n * a.K + kg * 8;
     const bf16_t* w2 = SW ? a.w2 + (size_t)n * a.K + kg * 8 : nullptr;
-    const int nks = a.K / 32, nsl = (nks + KSL - 1) / KSL;
 
     f32x4 acc[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 wr[RING][NM][KPW];
-    u32x4 xs[CPT];
     auto load_w = [&](bf16x8 (&wf)[NM][KPW], int s) __attribute__((always_inline)) {
 #pragma unroll
         for (int c = 0; c < KPW; ++c) {
-            const int ks = s * KSL + kq * KPW + c;
-            if (ks < nks) {
-                wf[0][c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(w1 + ks * 32));
-                if (SW) wf[NM - 1][c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(w2 + ks * 32));
-            }
-        }
-    };
-    auto load_x = [&](int s) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            const int chunk = tid + i * 512;
-            const int row = chunk / (KSL * 4), col = chunk % (KSL * 4);
-            int m = m0 + row;
-            m = m < a.M ? m : a.M - 1;
-            // k-steps past the end of K re-read the last valid one (never multiplied)
-            const int ks = min(s * KSL + col / 4, nks - 1);
-            xs[i] = *reinterpret_cast<const u32x4*>(a.x + (size_t)m * a.K + ks * 32 + (col & 3) * 8);
-        }
-    };
-    auto store_x = [&](int buf) __attribute__((always_inline)) {
-        char* xb = smem + buf * (NG * 32 * XS);
-#pragma unroll
-        for (int i = 0; i < CPT; ++i) {
-            const int chunk = tid + i * 512;
-            const int row = chunk / (KSL * 4), col = chunk % (KSL * 4);
-            *reinterpret_cast<u32x4*>(xb + row * XS + col * 16) = xs[i];
+            const int ko = (s * KSL + kq * KPW + c) * 32;
+            wf[0][c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(w1 + ko));
+            if (SW) wf[NM - 1][c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(w2 + ko));
         }
     };
     auto body = [&](bf16x8 (&cur)[NM][KPW], bf16x8 (&ahead)[NM][KPW], int s) __attribute__((always_inline)) {
         if (s + PD < nsl) load_w(ahead, s + PD);
-        const bool has_next = s + 1 < nsl;
-        if (has_next) load_x(s + 1);
-        const char* xb = smem + (s & 1) * (NG * 32 * XS);
+        const char* xb = smem + (s % NBUF) * XBUF;
 #pragma unroll
         for (int c = 0; c < KPW; ++c) {
-            const int kc = kq * KPW + c;
-            if (s * KSL + kc < nks) {
+            const int ch = (kq * KPW + c) * 4 + kg;            // logical 16-B chunk of the row
 #pragma unroll
-                for (int g = 0; g < NG; ++g) {
-                    if (m0 + g * 32 < a.M) {
-                        const bf16x8 xl = *reinterpret_cast<const bf16x8*>(xb + (g * 32 + lrow) * XS + kc * 64 + kg * 16);
-                        const bf16x8 xh = *reinterpret_cast<const bf16x8*>(xb + (g * 32 + 16 + lrow) * XS + kc * 64 + kg * 16);
+            for (int g = 0; g < NG; ++g) {
+                if (m0 + g * 32 < a.M) {
+                    const bf16x8 xl = *reinterpret_cast<const bf16x8*>(xb + (g * 32 + lrow) * XROW + ((ch ^ lrow) << 4));
+                    const bf16x8 xh = *reinterpret_cast<const bf16x8*>(xb + (g * 32 + 16 + lrow) * XROW + ((ch ^ lrow) << 4));
 #pragma unroll
-                        for (int q = 0; q < NM; ++q) {
-                            acc[(g * NM + q) * 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[q][c], xl, acc[(g * NM + q) * 2], 0, 0, 0);
-                            acc[(g * NM + q) * 2 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[q][c], xh, acc[(g * NM + q) * 2 + 1], 0, 0, 0);
-                        }
+                    for (int q = 0; q < NM; ++q) {
+                        acc[(g * NM + q) * 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[q][c], xl, acc[(g * NM + q) * 2], 0, 0, 0);
+                        acc[(g * NM + q) * 2 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[q][c], xh, acc[(g * NM + q) * 2 + 1], 0, 0, 0);
                     }
                 }
             }
         }
-        // buffer (s+1)&1 was last read in body(s-1), which ended with a barrier
-        if (has_next) store_x((s + 1) & 1);
-        __syncthreads();
+        __builtin_amdgcn_s_barrier();      // the loader waves arrive here once slice s+1 is in LDS
     };
 
 #pragma unroll
     for (int p = 0; p < PD; ++p)
         if (p < nsl) load_w(wr[p], p);
-    load_x(0);
-    store_x(0);
-    __syncthreads();
+    __builtin_amdgcn_s_barrier();          // x slice 0
     for (int s0 = 0; s0 < nsl; s0 += RING) {
 #pragma unroll
         for (int r = 0; r < RING; ++r)
             if (s0 + r < nsl) body(wr[r], wr[(r + PD) % RING], s0 + r);
     }
+    __builtin_amdgcn_s_barrier();          // every x read done, loader tail requests landed
 
     // ---- the KQ partial tiles of a row set meet in LDS (every x buffer read ended at the last barrier)
     f32x4* red = reinterpret_cast<f32x4*>(smem);           // [wave][NI][64 lanes]
@@ -134,7 +147,7 @@ __global__ __launch_bounds__(512) void gemm_mid_kernel(GemmArgs a) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) red[(wave * NI + i) * 64 + lane] = acc[i];
     }
-    __syncthreads();
+    __syncthreads();                       // (the loader waves execute the matching barrier and leave)
     if (kq > 0) return;
 #pragma unroll
     for (int p = 1; p < KQ; ++p)
@@ -182,13 +195,13 @@ __global__ __launch_bounds__(512) void gemm_mid_kernel(GemmArgs a) {
 
 template <int EPI, int NG>
 int launch_mid(const GemmArgs& a, hipStream_t s) {
-    constexpr int lds = 2 * NG * 32 * XS;
+    constexpr int lds = NBUF * NG * 32 * XROW;
     static bool attr = false;
     if (!attr && lds > 48 * 1024) {
         DH_HIP(hipFuncSetAttribute((const void*)gemm_mid_kernel<EPI, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr = true;
     }
-    dim3 grid(cdiv(a.N, 16 * MidShape<EPI>::RS), cdiv(a.M, NG * 32)), block(512);
+    dim3 grid(cdiv(a.N, 16 * MidShape<EPI>::RS), cdiv(a.M, NG * 32)), block(640);
     hipLaunchKernelGGL((gemm_mid_kernel<EPI, NG>), grid, block, lds, s, a);
     DH_LAUNCH_CHECK();
     return 0;
@@ -206,7 +219,7 @@ int launch_ng(const GemmArgs& a, hipStream_t s) {
 int g_mid = 1;
 
 bool dh_linear_mid_ok(const GemmArgs& a, int epilogue) {
-    return g_mid != 0 && a.K % 32 == 0 && a.N % 16 == 0 && a.M <= 256 &&
+    return g_mid != 0 && a.K % (KSL * 32) == 0 && a.N % 16 == 0 && a.M <= 256 &&
            (epilogue == DH_EPI_PLAIN || epilogue == DH_EPI_SWIGLU || epilogue == DH_EPI_ADAPTER);
 }
 

@@ -14,14 +14,14 @@ for M in (32, 64, 128, 256):
     x = torch.randn(M, d, device=D).bfloat16()
     ref_s = ref_h = None
     if M <= 32:
-        lib.dh_set_tuning(3, 0)
+        lib.dh_set_tuning(3, 0); lib.dh_set_tuning(4, 0)
         ref_s = ops.linear(x, W1[0], epilogue=ops.EPI_SWIGLU, w2=W2[0]).float()
         ref_h = ops.linear(x, Wl[0], epilogue=ops.EPI_ADAPTER, scale=sc, bias=bi).float()
         t = bench(lambda i: ops.linear(x, W1[i % L], epilogue=ops.EPI_SWIGLU, w2=W2[i % L]))
         print(f"M={M} swiglu skinny: {t:6.1f} us")
         t = bench(lambda i: ops.linear(x, Wl[i % 3], epilogue=ops.EPI_ADAPTER, scale=sc, bias=bi))
         print(f"M={M} lm_head skinny: {t:6.1f} us")
-    lib.dh_set_tuning(3, 1)
+    lib.dh_set_tuning(3, 1); lib.dh_set_tuning(4, 2)   # decode-phase kernels whatever M
     ys = ops.linear(x, W1[0], epilogue=ops.EPI_SWIGLU, w2=W2[0]).float()
     yh = ops.linear(x, Wl[0], epilogue=ops.EPI_ADAPTER, scale=sc, bias=bi).float()
     # fp32 torch reference with the same rounding points
