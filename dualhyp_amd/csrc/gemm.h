@@ -16,6 +16,7 @@ struct GemmArgs {
     int xa_ld, split0, split1;
     float lora_scale;
     int nb_n, nb_m;
+    int gm;            // m-tiles per band of the 256-tile kernel's block order
 };
 
 
@@ -31,6 +32,7 @@ extern int g_mid;            // 1: the decode phase uses the LDS-staged-x stream
 // M >= 256: 256 x 256 x 64 tiles, one block per CU (gemm256.hip)
 int dh_linear_256(GemmArgs a, int epilogue, hipStream_t s);
 extern int g_linear_phase;
+extern int g_gemm_gm;
 extern int g_gemm_variant;   // 1: use the 256-tile kernel when the shape allows, 0: always 128-tile
 
 // dh_linear_bf16 with an explicit kernel choice.  kernel: 0 = by shape (M <= 32 -> streaming),

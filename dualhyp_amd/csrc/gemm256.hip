@@ -33,7 +33,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
         const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int tm = tile / a.nb_n, tn = tile % a.nb_n;
+    // tiles are walked in bands of `gm` m-tiles, m fastest: the ~32 blocks an XCD runs at a time then form a
+    // gm x (32/gm) rectangle that shares gm x-tile streams and 32/gm W-tile streams through its L2
+    // instead of 1 + 32 (row-major); a.gm = 1 is the row-major order
+    int tm, tn;
+    {
+        const int gm = a.gm, band = tile / (gm * a.nb_n), within = tile - band * (gm * a.nb_n);
+        const int rows = min(gm, a.nb_m - band * gm);
+        tm = band * gm + within % rows;
+        tn = within / rows;
+    }
     const int m0 = tm * BT2;
     const int n0 = (EPI == DH_EPI_SWIGLU) ? tn * 128 : tn * BT2;
 
@@ -306,7 +315,10 @@ int launch(const GemmArgs& a, hipStream_t s) {
 }  // namespace
 
 // argument checks are done by dh_linear_impl (gemm.hip)
+int g_gemm_gm = 0;   // 0: by shape (tools/tune_gemm.py: 4 for the SwiGLU pair, 16 otherwise), else forced
+
 int dh_linear_256(GemmArgs a, int epilogue, hipStream_t s) {
+    a.gm = g_gemm_gm > 0 ? g_gemm_gm : (epilogue == DH_EPI_SWIGLU ? 4 : 16);
     a.nb_m = cdiv(a.M, BT2);
     a.nb_n = (epilogue == DH_EPI_SWIGLU) ? cdiv(a.N, 128) : cdiv(a.N, BT2);
     switch (epilogue) {

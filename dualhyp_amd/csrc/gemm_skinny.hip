@@ -396,6 +396,7 @@ extern "C" int dh_set_tuning(int key, int value) {
     if (key == 2) { g_swiglu2 = value; return 0; }
     if (key == 3) { g_mid = value; return 0; }
     if (key == 4) { g_linear_phase = value; return 0; }
+    if (key == 5 && value >= 0) { g_gemm_gm = value; return 0; }
     dh_set_error("dh_set_tuning: unknown key %d", key);
     return 1;
 }

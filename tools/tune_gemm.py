@@ -25,8 +25,9 @@ def bench(fn, n=12):
     for i in range(n): fn(i)
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n * 1e-3
-for variant in (1, 2):
-    lib.dh_set_tuning(1, variant)
+import itertools
+for variant, gm in itertools.product((2,), (1, 2, 4, 8, 16, 32)):
+    lib.dh_set_tuning(1, variant); lib.dh_set_tuning(5, gm); variant = f'{variant} gm={gm}'
     t = bench(lambda i: ops.linear(x, Wq[i % L], epilogue=ops.EPI_LORA, xa=xa, lora_b=Bq, splits=(2048, 2304), out=yq))
     print(f"variant {variant} qkv+lora   : {t*1e6:7.1f} us {2*M*2560*d/t/1e12:7.1f} TF")
     t = bench(lambda i: ops.linear(x, Wp[i % L], resid=res, out=yd))
