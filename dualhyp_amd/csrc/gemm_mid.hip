@@ -6,15 +6,14 @@
 //           AND fc_2) and KSL/KQ of the 4 k-steps of every slice, so a block covers only 16*RS output
 //           columns and even N = 5632 puts 176 blocks on the chip (SWIGLU: RS 2 x KQ 4, else 4 x 2)
 //   W     : global -> VGPR, ring of 8 slices per wave: 14 KiB in flight per wave, 112 KiB per block
-//           (6 slices for SWIGLU with 4 row groups: the register budget at 10 waves is 170 VGPRs)
 //   x     : rows [m0, m0 + 32*NG) x 128 k per slice, global -> LDS directly (global_load_lds, 16 B per
 //           lane) by the two loader waves, 4 buffers, requested 3 slices ahead; 256-B rows, 16-B chunk
 //           index XOR (row & 15) applied on the SOURCE address so the fragment reads are conflict free
 //   sync  : one s_barrier per slice; only the loader waves wait on a counted s_waitcnt (vmcnt is an
 //           in-order counter: x requests issued by a compute wave would drain its W queue every slice)
 //   MFMA  : v_mfma_f32_16x16x32_bf16, C^T[16 n][16 m] += W[16 n][32 k] · x[16 m][32 k]^T
-//   reduce: the KQ partial accumulators meet in LDS (the x buffers are free by then), summed in
-//           K-part order by the first wave of each row set, which also runs the epilogue
+//   reduce: the KQ partial accumulators meet in LDS (the x buffers are free by then); output tile pair t is
+//           summed in K-part order and finished by wave t % KQ of its row set
 //   grid  : (N / (16*RS), ceil(M / (32*NG)))
 // The summation order of an output is fixed by K alone (KQ interleaved chains, k ascending in each),
 // whatever M and NG: a row's result does not depend on how many other rows ride along (batch
@@ -38,7 +37,7 @@ struct MidShape {
     static constexpr int KPW = KSL / KQ;       // k-steps per wave per slice
 };
 // W slices held per wave (RING-1 in flight + the one being multiplied); 170 VGPRs per wave at 10 waves
-template <int EPI, int NG> constexpr int mid_ring() { return (EPI == DH_EPI_SWIGLU && NG == 4) ? 6 : 8; }
+template <int EPI, int NG> constexpr int mid_ring() { return 8; }
 
 template <int EPI, int NG>
 __global__ __launch_bounds__(640) void gemm_mid_kernel(GemmArgs a) {
@@ -141,18 +140,19 @@ __global__ __launch_bounds__(640) void gemm_mid_kernel(GemmArgs a) {
     }
     __builtin_amdgcn_s_barrier();          // every x read done, loader tail requests landed
 
-    // ---- the KQ partial tiles of a row set meet in LDS (every x buffer read ended at the last barrier)
+    // ---- the KQ partial tiles of a row set meet in LDS (every x buffer read ended at the last barrier).
+    // Output tile pair t = (g, h) is finished by K-part t % KQ: every wave parks the tiles it does not
+    // own, then sums its own in K-part order 0..KQ-1 (its register value taking its place in that order).
     f32x4* red = reinterpret_cast<f32x4*>(smem);           // [wave][NI][64 lanes]
-    if (kq > 0) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) red[(wave * NI + i) * 64 + lane] = acc[i];
+    for (int t = 0; t < NG * 2; ++t) {
+        if (t % KQ != kq) {
+            const int g = t >> 1, h = t & 1;
+#pragma unroll
+            for (int q = 0; q < NM; ++q) red[(wave * NI + (g * NM + q) * 2 + h) * 64 + lane] = acc[(g * NM + q) * 2 + h];
+        }
     }
     __syncthreads();                       // (the loader waves execute the matching barrier and leave)
-    if (kq > 0) return;
-#pragma unroll
-    for (int p = 1; p < KQ; ++p)
-#pragma unroll
-        for (int i = 0; i < NI; ++i) acc[i] += red[((p * RS + rs) * NI + i) * 64 + lane];
 
     // C layout: col (m) = lane & 15, rows (n) = 4*(lane>>4) + reg -> 4 consecutive n per lane
     const int nn = n0 + kg * 4;
@@ -166,31 +166,41 @@ __global__ __launch_bounds__(640) void gemm_mid_kernel(GemmArgs a) {
         }
     }
 #pragma unroll
-    for (int g = 0; g < NG; ++g)
+    for (int t = 0; t < NG * 2; ++t) {
+        if (t % KQ != kq) continue;
+        const int g = t >> 1, h = t & 1;
+        const int m = m0 + g * 32 + 16 * h + lrow;
+        if (m0 + g * 32 >= a.M) continue;
+        f32x4 tot[NM];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int m = m0 + g * 32 + 16 * h + lrow;
-            if (m >= a.M) continue;
-            float o[4];
+        for (int q = 0; q < NM; ++q) {
+            const int i = (g * NM + q) * 2 + h;
+            f32x4 sum = kq == 0 ? acc[i] : red[((0 * RS + rs) * NI + i) * 64 + lane];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (SW) {
-                    const float gt = rbf(acc[(g * NM) * 2 + h][r]), up = rbf(acc[(g * NM + NM - 1) * 2 + h][r]);
-                    o[r] = rbf(gt / (1.0f + expf(-gt))) * up;
-                } else {
-                    o[r] = rbf(acc[(g * NM) * 2 + h][r]);
-                    if (EPI == DH_EPI_ADAPTER) o[r] = rbf(va[r] * rbf(o[r] + vb[r]));
-                }
-            }
-            if (!SW && a.resid != nullptr) {
-                const uint2 rv = *reinterpret_cast<const uint2*>(a.resid + (size_t)m * a.N + nn);
-                const bf16_t* rp = reinterpret_cast<const bf16_t*>(&rv);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = bf2f(rp[r]) + o[r];
-            }
-            const uint2 pk = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
-            *reinterpret_cast<uint2*>(a.y + (size_t)m * a.N + nn) = pk;
+            for (int p = 1; p < KQ; ++p) sum += (p == kq) ? acc[i] : red[((p * RS + rs) * NI + i) * 64 + lane];
+            tot[q] = sum;
         }
+        if (m >= a.M) continue;
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (SW) {
+                const float gt = rbf(tot[0][r]), up = rbf(tot[NM - 1][r]);
+                o[r] = rbf(gt / (1.0f + expf(-gt))) * up;
+            } else {
+                o[r] = rbf(tot[0][r]);
+                if (EPI == DH_EPI_ADAPTER) o[r] = rbf(va[r] * rbf(o[r] + vb[r]));
+            }
+        }
+        if (!SW && a.resid != nullptr) {
+            const uint2 rv = *reinterpret_cast<const uint2*>(a.resid + (size_t)m * a.N + nn);
+            const bf16_t* rp = reinterpret_cast<const bf16_t*>(&rv);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = bf2f(rp[r]) + o[r];
+        }
+        const uint2 pk = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+        *reinterpret_cast<uint2*>(a.y + (size_t)m * a.N + nn) = pk;
+    }
 }
 
 template <int EPI, int NG>
