@@ -150,6 +150,11 @@ def main() -> None:
         utt = B * a.steps * world
         flops = gemm_flops_per_prefill(cfg, B * PROMPT_LEN, B) * a.steps
         achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        traffic = None   # HBM-side bytes per launch from the committed PMC passes
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_gemm.json")
+        if os.path.exists(pmc):
+            with open(pmc) as fh:
+                traffic = json.load(fh).get("traffic_bytes_per_launch_mean")
         result = {
             "metric": "corrected utterances/sec (TinyLlama-1.1B, 5+5 hyps, 512->64 tok)",
             "value": utt / dt, "unit": "utterances/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -160,9 +165,10 @@ def main() -> None:
                        "batch_per_gpu": B, "prompt_tokens": PROMPT_LEN, "new_tokens": NEW_TOKENS,
                        "parallelism": f"replicas x{world}", "batches_in_flight_per_gpu": G, "schedule": a.schedule,
                        "decode_rows_per_launch": B * min(G, a.steps) if a.schedule == "merged" else B},
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (prefill GEMMs: qkv+LoRA, proj+LoRA, fc_1/fc_2 SwiGLU, mlp proj)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_nt256_kernel (prefill GEMMs: qkv+LoRA, proj+LoRA, fc_1/fc_2 SwiGLU, mlp proj)",
                          "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "traffic_source": "profiles/r01_pmc_gemm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)",
                          "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
                          "prefill_attention_ms_per_step": attn_ms / max(a.steps, 1)},
         }

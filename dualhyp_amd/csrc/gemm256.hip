@@ -315,10 +315,10 @@ int launch(const GemmArgs& a, hipStream_t s) {
 }  // namespace
 
 // argument checks are done by dh_linear_impl (gemm.hip)
-int g_gemm_gm = 0;   // 0: by shape (tools/tune_gemm.py: 4 for the SwiGLU pair, 16 otherwise), else forced
+int g_gemm_gm = 0;   // 0: default 4 (4 x 8 tile rectangles per XCD: fewest operand streams, tools/tune_gemm.py + PMC), else forced
 
 int dh_linear_256(GemmArgs a, int epilogue, hipStream_t s) {
-    a.gm = g_gemm_gm > 0 ? g_gemm_gm : (epilogue == DH_EPI_SWIGLU ? 4 : 16);
+    a.gm = g_gemm_gm > 0 ? g_gemm_gm : 4;
     a.nb_m = cdiv(a.M, BT2);
     a.nb_n = (epilogue == DH_EPI_SWIGLU) ? cdiv(a.N, 128) : cdiv(a.N, BT2);
     switch (epilogue) {
