@@ -128,11 +128,7 @@ def validate(model, batches: Iterable[Dict[str, torch.Tensor]]) -> float:
     return sum(losses) / max(len(losses), 1)
 
 
-def save_checkpoint(model, path) -> None:
-    """`fabric.save(path, {"model": model})` (finetune/ger.py:356-358): whole state dict, reference keys."""
-    sd = {k: v.detach().to("cpu") for k, v in model.state_dict().items()}
-    Path(path).parent.mkdir(parents=True, exist_ok=True)
-    torch.save({"model": sd}, str(path))
+from .checkpoint import save_checkpoint  # noqa: E402,F401  (finetune/ger.py:356-358)
 
 
 def fit(model, train_examples: Sequence[Dict[str, torch.Tensor]], collate: Callable, cfg: TrainConfig, *,

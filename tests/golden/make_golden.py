@@ -80,7 +80,7 @@ def import_reference():
 
 def save(name: str, tensors: dict, meta: dict | None = None) -> None:
     from safetensors.torch import save_file
-    t = {k: v.detach().contiguous().cpu() for k, v in tensors.items()}
+    t = {k: v.detach().contiguous().cpu().clone() for k, v in tensors.items()}
     md = {"meta": json.dumps(meta or {})}
     save_file(t, str(HERE / f"{name}.safetensors"), metadata=md)
     sz = (HERE / f"{name}.safetensors").stat().st_size
@@ -337,6 +337,49 @@ def gen_misc(rutils, rprompts) -> None:
     print("wrote prompts.json")
 
 
+def gen_convert(rlora) -> None:
+    """HF Llama checkpoint -> lit state dict by the reference's own converter
+    (scripts/convert_hf_checkpoint.py:117-202), fed in two shards with layer 1's q and k/v split
+    across them.  Tensors hold distinct integers so the fixture pins the exact row permutation."""
+    import scripts.convert_hf_checkpoint as rconv
+    kw = dict(name="convert-tiny", block_size=32, vocab_size=60, padding_multiple=4, n_layer=2, n_head=4, n_embd=64,
+              n_query_groups=2, rotary_percentage=1.0, parallel_residual=False, bias=False, _norm_class="RMSNorm",
+              norm_eps=1e-5, _mlp_class="LLaMAMLP", intermediate_size=96)
+    cfg = rlora.Config(**kw)
+    hs, G, d, I, V = cfg.head_size, cfg.n_query_groups, cfg.n_embd, cfg.intermediate_size, cfg.padded_vocab_size
+    counter = [0]
+
+    def t(*shape):
+        n = math.prod(shape)
+        out = (torch.arange(n, dtype=torch.float32) + counter[0]).reshape(shape)
+        counter[0] += n
+        return out
+
+    hf = {"model.embed_tokens.weight": t(V, d), "model.norm.weight": t(d), "lm_head.weight": t(V, d)}
+    for l in range(cfg.n_layer):
+        p = f"model.layers.{l}."
+        hf.update({p + "input_layernorm.weight": t(d), p + "post_attention_layernorm.weight": t(d),
+                   p + "self_attn.q_proj.weight": t(d, d), p + "self_attn.k_proj.weight": t(G * hs, d),
+                   p + "self_attn.v_proj.weight": t(G * hs, d), p + "self_attn.o_proj.weight": t(d, d),
+                   p + "self_attn.rotary_emb.inv_freq": t(hs // 2),
+                   p + "mlp.gate_proj.weight": t(I, d), p + "mlp.up_proj.weight": t(I, d), p + "mlp.down_proj.weight": t(d, I)})
+    late = {k for k in hf if k.startswith("model.layers.1.self_attn.k_proj") or k.startswith("model.layers.1.self_attn.v_proj")
+            or k.startswith("model.layers.1.mlp") or k in ("model.norm.weight", "lm_head.weight")}
+    shard1 = {k: v for k, v in hf.items() if k not in late}
+    shard2 = {k: v for k, v in hf.items() if k in late}
+    out, qkv = {}, {}
+    rconv.copy_weights_hf_llama(cfg, qkv, out, shard1)
+    rconv.copy_weights_hf_llama(cfg, qkv, out, shard2)
+    assert not qkv
+    # tied-embedding checkpoints (no lm_head.weight in the HF files)
+    out_tied, qkv = {}, {}
+    rconv.copy_weights_hf_llama(cfg, qkv, out_tied, {k: v for k, v in hf.items() if k != "lm_head.weight"})
+    tensors = {f"hf.{k}": v for k, v in hf.items()}
+    tensors.update({f"lit.{k}": v for k, v in out.items()})
+    tensors["lit_tied.lm_head.weight"] = out_tied["lm_head.weight"]
+    save("convert_hf_llama", tensors, {"config": {k: v for k, v in kw.items()}, "shard2_keys": sorted(late)})
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
@@ -347,6 +390,8 @@ def main() -> None:
     want = lambda k: (not a.only) or a.only == k
     if want("misc"):
         gen_misc(rutils, rprompts)
+    if want("convert"):
+        gen_convert(rlora)
     if want("tiny"):
         gen_tiny(rlora, rutils, rgenerate, "tiny_r4", "parity-tiny", r=4, seed=1337)
         gen_tiny(rlora, rutils, rgenerate, "tiny_hs128_r16", "parity-hs128", r=16, seed=4242)
