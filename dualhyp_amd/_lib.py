@@ -58,6 +58,8 @@ SIGNATURES = {
     "dh_engine_create": (I, [C.POINTER(ModelDesc), I, I, I, C.POINTER(P)]),
     "dh_engine_destroy": (None, [P]),
     "dh_engine_device_bytes": (I64, [P]),
+    "dh_cross_entropy_fwd": (I, [P, I, P, P, P, I, I, P]),
+    "dh_cross_entropy_bwd": (I, [P, I, P, P, P, P, I, I, P]),
     "dh_engine_forward": (I, [P, P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), I, P, P, P]),
     "dh_engine_forward_at": (I, [P, P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), I, I, P, P, P]),
     "dh_engine_set_cpu_rsqrt_emulation": (I, [P, I, I]),

@@ -140,6 +140,30 @@ def sample(logits: torch.Tensor, tokens: torch.Tensor, length: torch.Tensor, don
                                      int(seed) & ((1 << 64) - 1), int(step), _stream()))
 
 
+def cross_entropy_fwd(logits: torch.Tensor, targets: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(loss_per_row fp32 [rows], lse fp32 [rows]); ignored rows (target -1) give 0; dh_cross_entropy_fwd."""
+    assert logits.dtype in (torch.bfloat16, torch.float32), f"logits must be bf16 or fp32, got {logits.dtype}"
+    lg = _dev(logits.reshape(-1, logits.size(-1)), logits.dtype, "logits")
+    tg = _dev(targets.reshape(-1), torch.int64, "targets")
+    assert tg.numel() == lg.size(0), f"{tg.numel()} targets for {lg.size(0)} rows"
+    loss = torch.empty(lg.size(0), dtype=torch.float32, device=lg.device)
+    lse = torch.empty_like(loss)
+    check(_lib.load().dh_cross_entropy_fwd(_p(lg), int(lg.dtype == torch.float32), _p(tg), _p(loss), _p(lse), lg.size(0),
+                                           lg.size(1), _stream()))
+    return loss, lse
+
+
+def cross_entropy_bwd(logits: torch.Tensor, targets: torch.Tensor, lse: torch.Tensor, grad_row: torch.Tensor) -> torch.Tensor:
+    """dlogits (same shape / dtype as logits); dh_cross_entropy_bwd."""
+    lg = _dev(logits.reshape(-1, logits.size(-1)), logits.dtype, "logits")
+    tg = _dev(targets.reshape(-1), torch.int64, "targets")
+    out = torch.empty_like(lg)
+    check(_lib.load().dh_cross_entropy_bwd(_p(lg), int(lg.dtype == torch.float32), _p(tg), _p(_dev(lse, torch.float32, "lse")),
+                                           _p(_dev(grad_row, torch.float32, "grad_row")), _p(out), lg.size(0), lg.size(1),
+                                           _stream()))
+    return out.view(logits.shape)
+
+
 def linear_partial(x: torch.Tensor, w: torch.Tensor, w_ext: Optional[torch.Tensor] = None, ksplit: int = 1) -> torch.Tensor:
     """fp32 partial sums [ksplit, M, n_main+n_ext] of x @ [w; w_ext].T (M <= 32); dh_linear_partial_bf16."""
     x, w = _dev(x, name="x"), _dev(w, name="w")

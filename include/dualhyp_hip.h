@@ -179,6 +179,18 @@ int dh_attn_bwd_bf16(const dh_bf16* q, const dh_bf16* k, const dh_bf16* v, const
 
 /* ------------------------------------------------------------------ token sampling */
 
+/* Token-level cross entropy, ignore_index = -1 — ger/utils.py:424-463 (F.cross_entropy on the
+ * autocast-upcast logits): loss[r] = logsumexp(logits[r,:]) - logits[r,target[r]] in fp32, 0 for
+ * ignored rows (target outside [0, vocab)); lse[r] is kept for the backward.  logits: [rows, vocab]
+ * bf16 (is_f32 = 0) or fp32 (is_f32 = 1).  The caller picks the normalisation (quirk Q5: chunked
+ * variants divide by ALL rows, chunk_size = 0 by the valid rows). */
+int dh_cross_entropy_fwd(const void* logits, int is_f32, const int64_t* targets, float* loss,
+                         float* lse, int rows, int vocab, void* stream);
+/* dlogits[r,c] = grad_row[r] * (softmax(logits[r,:])[c] - [c == target[r]]), 0 for ignored rows;
+ * same dtype as logits. */
+int dh_cross_entropy_bwd(const void* logits, int is_f32, const int64_t* targets, const float* lse,
+                         const float* grad_row, void* dlogits, int rows, int vocab, void* stream);
+
 /* One decode-loop tail per sequence — generate/base.py:62-80:
  *   l = logits/temperature (bf16) ; keep l >= k-th largest ; softmax ; multinomial.
  * top_k == 1 is resolved as arg-max with the LOWEST index among equal maxima (the reference
