@@ -66,12 +66,19 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    # rehearsal on a one-GPU box: DUALHYP_BENCH_REHEARSAL=1 puts every rank on cuda:0 and uses gloo
+    rehearsal = os.environ.get("DUALHYP_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     from dualhyp_amd import GPT, Config, GER_LORA
@@ -141,7 +148,7 @@ def main() -> None:
         e.set_timing(False)
     assert all(o.numel() == PROMPT_LEN + NEW_TOKENS for out in outs for o in out)
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device="cpu" if rehearsal else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
