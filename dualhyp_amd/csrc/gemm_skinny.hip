@@ -265,16 +265,18 @@ __global__ __launch_bounds__(512, 2) void gemm_skinny_partial_kernel(const bf16_
 // work on the SAME K-slice, so the x slice [32*NG x 32*KPS] is staged once per block in LDS (x is
 // 2/3 of the load instructions when every wave fetches its own fragments) and no cross-wave
 // reduction is needed: each wave stores its fp32 tile straight from the accumulators.  NG 32-row
-// groups of x (several batches decoded in one launch) reuse the W fragments held in registers.
+// groups of x (several batches decoded in one launch) reuse the W fragments held in registers; when
+// NG groups do not fit in LDS they pass through it NGL at a time (W is still streamed once).
 //   grid (ceil(N/128), ksplit, ceil(M / (32*NG))), K-slice = KPS k-steps of 32.
-template <int KPS, int NG>
+template <int KPS, int NG, int NGL>
 __global__ __launch_bounds__(512, NG == 1 ? 2 : 1) void gemm_skinny_rows_kernel(const bf16_t* __restrict__ x,
                                                                               const bf16_t* __restrict__ w,
                                                                               const bf16_t* __restrict__ w_ext,
                                                                               float* __restrict__ y32, int M, int n_main,
                                                                               int N, int K) {
+    static_assert(NG % NGL == 0, "LDS rounds must divide the row groups");
     constexpr int XS = KPS * 64 + 16;                      // padded row stride of the x slice (bytes)
-    extern __shared__ __attribute__((aligned(16))) char sx[];   // [NG*32][XS]
+    extern __shared__ __attribute__((aligned(16))) char sx[];   // [NGL*32][XS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, kg = lane >> 4;
     const int n0 = blockIdx.x * 128 + wave * 16;
@@ -289,38 +291,44 @@ __global__ __launch_bounds__(512, NG == 1 ? 2 : 1) void gemm_skinny_rows_kernel(
 #pragma unroll
     for (int c = 0; c < KPS; ++c)
         if (c < ks_cnt) wf[c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wrow + c * 32));
-    // stage the x slice: 32*NG rows x ks_cnt*4 chunks of 16 B
-#pragma unroll
-    for (int i = 0; i < NG * 32 * KPS * 4 / 512; ++i) {
-        const int c = tid + i * 512;
-        const int row = c / (KPS * 4), col = c % (KPS * 4);
-        if (col < ks_cnt * 4) {
-            int m = m0 + row;
-            m = m < M ? m : M - 1;
-            *reinterpret_cast<uint4*>(sx + row * XS + col * 16) =
-                *reinterpret_cast<const uint4*>(x + (size_t)m * K + ks_begin * 32 + col * 8);
-        }
-    }
-    __syncthreads();
     const int nn = n0 + kg * 4;
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const int mg = m0 + g * 32;
-        if (mg >= M) break;
-        f32x4 acc_lo = {0.f, 0.f, 0.f, 0.f}, acc_hi = {0.f, 0.f, 0.f, 0.f};
+    for (int r0 = 0; r0 < NG; r0 += NGL) {
+        const int mr = m0 + r0 * 32;                       // first row of this LDS round
+        if (mr >= M) break;
+        if (r0 > 0) __syncthreads();                       // the previous round's fragment reads are done
+        // stage the x slice: 32*NGL rows x ks_cnt*4 chunks of 16 B
 #pragma unroll
-        for (int c = 0; c < KPS; ++c) {
-            if (c < ks_cnt) {
-                const bf16x8 xl = *reinterpret_cast<const bf16x8*>(sx + (g * 32 + lrow) * XS + c * 64 + kg * 16);
-                const bf16x8 xh = *reinterpret_cast<const bf16x8*>(sx + (g * 32 + 16 + lrow) * XS + c * 64 + kg * 16);
-                acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c], xl, acc_lo, 0, 0, 0);
-                acc_hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c], xh, acc_hi, 0, 0, 0);
+        for (int i = 0; i < NGL * 32 * KPS * 4 / 512; ++i) {
+            const int c = tid + i * 512;
+            const int row = c / (KPS * 4), col = c % (KPS * 4);
+            if (col < ks_cnt * 4) {
+                int m = mr + row;
+                m = m < M ? m : M - 1;
+                *reinterpret_cast<uint4*>(sx + row * XS + col * 16) =
+                    *reinterpret_cast<const uint4*>(x + (size_t)m * K + ks_begin * 32 + col * 8);
             }
         }
-        if (nn < N) {
-            float* out = y32 + (size_t)blockIdx.y * M * N + nn;
-            if (mg + lrow < M) *reinterpret_cast<f32x4*>(out + (size_t)(mg + lrow) * N) = acc_lo;
-            if (mg + 16 + lrow < M) *reinterpret_cast<f32x4*>(out + (size_t)(mg + 16 + lrow) * N) = acc_hi;
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < NGL; ++g) {
+            const int mg = mr + g * 32;
+            if (mg >= M) break;
+            f32x4 acc_lo = {0.f, 0.f, 0.f, 0.f}, acc_hi = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < KPS; ++c) {
+                if (c < ks_cnt) {
+                    const bf16x8 xl = *reinterpret_cast<const bf16x8*>(sx + (g * 32 + lrow) * XS + c * 64 + kg * 16);
+                    const bf16x8 xh = *reinterpret_cast<const bf16x8*>(sx + (g * 32 + 16 + lrow) * XS + c * 64 + kg * 16);
+                    acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c], xl, acc_lo, 0, 0, 0);
+                    acc_hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c], xh, acc_hi, 0, 0, 0);
+                }
+            }
+            if (nn < N) {
+                float* out = y32 + (size_t)blockIdx.y * M * N + nn;
+                if (mg + lrow < M) *reinterpret_cast<f32x4*>(out + (size_t)(mg + lrow) * N) = acc_lo;
+                if (mg + 16 + lrow < M) *reinterpret_cast<f32x4*>(out + (size_t)(mg + 16 + lrow) * N) = acc_hi;
+            }
         }
     }
 }
@@ -328,14 +336,17 @@ __global__ __launch_bounds__(512, NG == 1 ? 2 : 1) void gemm_skinny_rows_kernel(
 template <int KPS, int NG>
 int launch_rows(const bf16_t* x, const bf16_t* w, const bf16_t* w_ext, float* y32, int M, int n_main, int N, int K,
                 int ksplit, hipStream_t s) {
-    constexpr int lds = NG * 32 * (KPS * 64 + 16);
+    constexpr int XS = KPS * 64 + 16;
+    constexpr int NGL = NG * 32 * XS <= 144 * 1024 ? NG : NG / 2;   // groups resident in LDS at once
+    constexpr int lds = NGL * 32 * XS;
+    static_assert(lds <= 160 * 1024, "x slice does not fit in LDS");
     static bool attr = false;
     if (!attr && lds > 48 * 1024) {
-        DH_HIP(hipFuncSetAttribute((const void*)gemm_skinny_rows_kernel<KPS, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        DH_HIP(hipFuncSetAttribute((const void*)gemm_skinny_rows_kernel<KPS, NG, NGL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr = true;
     }
     dim3 grid((N + 127) / 128, ksplit, cdiv(M, NG * 32)), block(512);
-    hipLaunchKernelGGL((gemm_skinny_rows_kernel<KPS, NG>), grid, block, lds, s, x, w, w_ext, y32, M, n_main, N, K);
+    hipLaunchKernelGGL((gemm_skinny_rows_kernel<KPS, NG, NGL>), grid, block, lds, s, x, w, w_ext, y32, M, n_main, N, K);
     DH_LAUNCH_CHECK();
     return 0;
 }
@@ -345,7 +356,8 @@ int launch_rows_ng(const bf16_t* x, const bf16_t* w, const bf16_t* w_ext, float*
                    int ksplit, hipStream_t s) {
     if (M <= 32) return launch_rows<KPS, 1>(x, w, w_ext, y32, M, n_main, N, K, ksplit, s);
     if (M <= 64) return launch_rows<KPS, 2>(x, w, w_ext, y32, M, n_main, N, K, ksplit, s);
-    return launch_rows<KPS, 4>(x, w, w_ext, y32, M, n_main, N, K, ksplit, s);
+    if (M <= 128) return launch_rows<KPS, 4>(x, w, w_ext, y32, M, n_main, N, K, ksplit, s);
+    return launch_rows<KPS, 8>(x, w, w_ext, y32, M, n_main, N, K, ksplit, s);
 }
 
 int g_skinny_variant = 1;   // 0: K split over the waves of a block, 1: row-parallel with LDS-staged x
