@@ -18,7 +18,7 @@ constexpr int MAXP = 16;    // most K-slices a partial-sum GEMM emits
 // grid (n_seq * n_groups), 512 threads.  qkv32: [n_part][n_seq][ldq] fp32, ldq = qkv_dim + n_ext;
 // columns [qkv_dim, qkv_dim+48) hold x·A^T of the q/k/v LoRA (when lora_b != null).
 template <int HS, int PMAX>
-__global__ __launch_bounds__(512) void attn_decode_fused_kernel(
+__global__ __launch_bounds__(512, HS == 64 ? 4 : 2) void attn_decode_fused_kernel(
     const float* __restrict__ qkv32, int n_part, int n_seq, int ldq, int qkv_dim,
     const bf16_t* __restrict__ lora_b, float lora_scale, int split0, int split1,
     const bf16_t* __restrict__ cos, const bf16_t* __restrict__ sin, const int32_t* __restrict__ seq_slot,
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(512) void attn_decode_fused_kernel(
 
     // ---- request the K / V^T operands of this wave's first PF tiles before anything else: they do
     // not depend on the new token, and their HBM latency hides under the LoRA/rope phase
-    constexpr int PF = HS == 64 ? 2 : 1;   // hs 128: two tiles of operands would spill
+    constexpr int PF = 1;   // one tile of operands in flight per wave: 128 VGPRs, two blocks per CU (hs 64)
     struct VF { bf16x8 v; };
     struct Tile { bf16x8 kf[KS]; VF vf[DT][2]; };
     Tile tl[PF];

@@ -25,9 +25,15 @@ def bench(fn, n=12):
     for i in range(n): fn(i)
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n * 1e-3
-import itertools
-for variant, gm in itertools.product((2,), (1, 2, 4, 8, 16, 32)):
-    lib.dh_set_tuning(1, variant); lib.dh_set_tuning(5, gm); variant = f'{variant} gm={gm}'
+outs = {}
+for variant in (1, 2, 3):
+    lib.dh_set_tuning(1, variant)
+    outs[variant] = (ops.linear(x, Wq[0], epilogue=ops.EPI_LORA, xa=xa, lora_b=Bq, splits=(2048, 2304)).clone(),
+                     ops.linear(x, W1[0], epilogue=ops.EPI_SWIGLU, w2=W2[0]).clone(), ops.linear(act, Wm[0], resid=res).clone())
+for v in (2, 3):
+    print(f"variant {v} == variant 1 bitwise:", [bool(torch.equal(a, b)) for a, b in zip(outs[1], outs[v])])
+for variant in (1, 2, 3):
+    lib.dh_set_tuning(1, variant)
     t = bench(lambda i: ops.linear(x, Wq[i % L], epilogue=ops.EPI_LORA, xa=xa, lora_b=Bq, splits=(2048, 2304), out=yq))
     print(f"variant {variant} qkv+lora   : {t*1e6:7.1f} us {2*M*2560*d/t/1e12:7.1f} TF")
     t = bench(lambda i: ops.linear(x, Wp[i % L], resid=res, out=yd))
