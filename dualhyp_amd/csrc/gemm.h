@@ -29,6 +29,14 @@ bool dh_linear_mid_ok(const GemmArgs& a, int epilogue);
 int dh_linear_mid(const GemmArgs& a, int epilogue, hipStream_t s);
 extern int g_mid;            // 1: the decode phase uses the LDS-staged-x streaming kernel for PLAIN/SWIGLU/ADAPTER
 
+// decode phase, > 64 rows: tiled kernel with the streaming kernels' summation order (gemm_dt.hip)
+bool dh_linear_dt_ok(const GemmArgs& a, int epilogue, int seg);
+int dh_linear_dt(const GemmArgs& a, int epilogue, int seg, hipStream_t s);
+bool dh_chain_ok(int M, int n_main, int n_ext, int K, int ksplit);
+int dh_chain_tiled(const bf16_t* x, const bf16_t* w, const bf16_t* w_ext, float* y32, int M, int n_main, int n_ext, int K,
+                   int kps, hipStream_t s);
+extern int g_dt_min_rows, g_chain_min_rows;
+
 // M >= 256: 256 x 256 x 64 tiles, one block per CU (gemm256.hip)
 int dh_linear_256(GemmArgs a, int epilogue, hipStream_t s);
 extern int g_linear_phase;

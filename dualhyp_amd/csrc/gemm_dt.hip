@@ -1,0 +1,242 @@
+// Decode-phase GEMMs for MORE than 64 rows (several batches decoded jointly): a tiled kernel with both
+// operands through LDS, bit-identical to the streaming kernels it replaces.
+//
+// Above ~64 rows the streaming kernels (gemm_skinny.hip rows kernel, gemm_mid.hip) stop being bound by
+// the weight stream: every wave re-reads the whole x slice from LDS for its 16 W rows (one MFMA per
+// 1-KiB fragment read — at 256 rows the LDS port is busy 4x longer than the matrix pipe) and the K-sliced
+// partial sums cost M*N*ksplit*4 bytes of stores.  Here a block owns a 128(m) x 128(n) tile, 4 waves of
+// 64 x 64 (8 fragment reads feed 16 MFMAs), K in 64-wide stages through a 4-deep LDS ring
+// (global_load_lds, source-side XOR swizzle as gemm.hip), and the full K is reduced in the block.
+//
+// Bit-compatibility: the streaming kernels define an output as chains of v_mfma_f32_16x16x32_bf16 over
+// CONTIGUOUS K segments (k ascending, fp32 accumulator from zero), the chains added in segment order
+// (rows kernel: K-slices of 8 or 16 k-steps, added by the consumer kernels; gemm_mid.hip: KQ K-parts,
+// added in its LDS reduction).  This kernel runs the same chains — same MFMA instruction and operand
+// roles, `cur` restarted at every segment boundary and folded into `tot` in order — so a row's result is
+// the same whichever kernel computed it (tests: test_linear_partial_wide_rows, test_joint_decode_*).
+//   MODE 0 : fp32 output [M][N] of x·[w; w_ext]^T (the sum of the rows kernel's partials)
+//   MODE 1 : SwiGLU pair, bf16 output; MODE 2 : adapter scale/bias; MODE 3 : plain (+ residual)
+//   grid   : m-tiles fastest, then n-tiles
+#include "common.h"
+#include "gemm.h"
+
+namespace {
+
+constexpr int TB = 128;                 // block tile edge (rows of x, rows of W)
+constexpr int BKD = 64;                 // K per stage (two k-steps of 32)
+constexpr int STAGE = 2 * TB * BKD * 2; // bytes per stage: W tile 16 KiB + x tile 16 KiB
+constexpr int NSTAGE = 4;                // ring: 3 stages in flight ahead of the one being multiplied
+
+__device__ __forceinline__ int swz7(int row) { return (row >> 1) & 7; }
+
+struct DtArgs {
+    const bf16_t* x;
+    const bf16_t* w;
+    const bf16_t* w2;      // MODE 0: w_ext (rows n_main..), MODE 1: fc_2
+    void* y;               // MODE 0: float [M][N], else bf16 [M][N]
+    const bf16_t* vec_a;
+    const bf16_t* vec_b;
+    const bf16_t* resid;
+    int M, N, K, n_main, seg;   // seg: k-steps per chain segment (even)
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void gemm_dt_kernel(DtArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // NSTAGE stages
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wm = wave & 1;
+    const int frow = lane & 15, kg = lane >> 4;
+    const int m_tiles = (a.M + TB - 1) / TB;
+    const int tm = blockIdx.x % m_tiles, tn = blockIdx.x / m_tiles;
+    const int m0 = tm * TB;
+    const int n0 = MODE == 1 ? tn * 64 : tn * TB;     // first output column of the block
+
+    // ---- staging sources: 16 + 16 one-KiB groups (8 rows of 128 B) per stage, 4 + 4 per wave
+    const bf16_t* srcA[4];
+    const bf16_t* srcB[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int R = wave * 4 + j;
+        const int row = R * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ swz7(row);
+        {
+            const bf16_t* base = a.w;
+            int n;
+            if (MODE == 1) {
+                // a wave's 64 LDS rows: 32 rows of fc_1 then the same 32 rows of fc_2
+                const int half = (row >> 5) & 1;
+                n = n0 + (row >> 6) * 32 + (row & 31);
+                n = n < a.N ? n : a.N - 1;
+                base = half ? a.w2 : a.w;
+            } else {
+                n = n0 + row;
+                n = n < a.N ? n : a.N - 1;
+                if (MODE == 0 && n >= a.n_main) { base = a.w2; n -= a.n_main; }
+            }
+            srcA[j] = base + (size_t)n * a.K + chunk * 8;
+        }
+        {
+            int m = m0 + row;
+            m = m < a.M ? m : a.M - 1;
+            srcB[j] = a.x + (size_t)m * a.K + chunk * 8;
+        }
+    }
+    auto stage = [&](int kt) __attribute__((always_inline)) {
+        char* sA = smem + (kt % NSTAGE) * STAGE;
+        char* sB = sA + STAGE / 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int R = wave * 4 + j;
+            glds16(srcA[j] + kt * BKD, sA + R * 1024);
+            glds16(srcB[j] + kt * BKD, sB + R * 1024);
+        }
+    };
+
+    f32x4 cur[4][4], tot[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            cur[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            tot[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    const int sw = swz7(frow);
+    const int offA = (wn * 64 + frow) * 128, offB = (wm * 64 + frow) * 128;
+    const int nk = a.K / BKD;
+    const int seg_kt = a.seg / 2;       // stages per chain segment
+
+    stage(0);
+    if (1 < nk) stage(1);
+    if (2 < nk) stage(2);
+    if (2 < nk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int in_seg = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // ring slot (kt+3) % 4 was last read in iteration kt-1, which ended with a barrier
+        if (kt + 3 < nk) stage(kt + 3);
+        const char* sA = smem + (kt % NSTAGE) * STAGE;
+        const char* sB = sA + STAGE / 2;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int co = ((ks * 4 + kg) ^ sw) << 4;
+            bf16x8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = *reinterpret_cast<const bf16x8*>(sA + offA + i * 2048 + co);
+                fb[i] = *reinterpret_cast<const bf16x8*>(sB + offB + i * 2048 + co);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    cur[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], cur[i][j], 0, 0, 0);
+        }
+        if (++in_seg == seg_kt || kt + 1 == nk) {     // end of a chain segment: fold it in, in order
+            in_seg = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    tot[i][j] += cur[i][j];
+                    cur[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+        }
+        // own share of stage kt+1 landed (stages kt+2, kt+3 may stay in flight), then everybody's
+        if (kt + 3 < nk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    // tot[i][j][r]: LDS row of W = wn*64 + i*16 + 4*kg + r ; m = m0 + wm*64 + j*16 + frow
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wm * 64 + j * 16 + frow;
+        if (m >= a.M) continue;
+        if (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int n = n0 + wn * 32 + i * 16 + kg * 4;
+                if (n >= a.N) continue;
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float gt = rbf(tot[i][j][r]), up = rbf(tot[i + 2][j][r]);
+                    o[r] = rbf(gt / (1.0f + expf(-gt))) * up;
+                }
+                *reinterpret_cast<uint2*>((bf16_t*)a.y + (size_t)m * a.N + n) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = n0 + wn * 64 + i * 16 + kg * 4;
+                if (n >= a.N) continue;
+                if (MODE == 0) {
+                    *reinterpret_cast<f32x4*>((float*)a.y + (size_t)m * a.N + n) = tot[i][j];
+                    continue;
+                }
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    o[r] = rbf(tot[i][j][r]);
+                    if (MODE == 2) o[r] = rbf(bf2f(a.vec_a[n + r]) * rbf(o[r] + bf2f(a.vec_b[n + r])));
+                }
+                if (MODE == 3 && a.resid != nullptr) {
+                    const uint2 rv = *reinterpret_cast<const uint2*>(a.resid + (size_t)m * a.N + n);
+                    const bf16_t* rp = reinterpret_cast<const bf16_t*>(&rv);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = bf2f(rp[r]) + o[r];
+                }
+                *reinterpret_cast<uint2*>((bf16_t*)a.y + (size_t)m * a.N + n) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+            }
+        }
+    }
+}
+
+template <int MODE>
+int launch_dt(const DtArgs& a, hipStream_t s) {
+    constexpr int lds = NSTAGE * STAGE;     // 128 KiB
+    static bool attr = false;
+    if (!attr) {
+        DH_HIP(hipFuncSetAttribute((const void*)gemm_dt_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr = true;
+    }
+    const int m_tiles = cdiv(a.M, TB), n_tiles = cdiv(a.N, MODE == 1 ? 64 : TB);
+    hipLaunchKernelGGL(gemm_dt_kernel<MODE>, dim3(m_tiles * n_tiles), dim3(256), lds, s, a);
+    DH_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+// Measured (tools/tune_dt.py, TinyLlama shapes): the tiled kernel beats gemm_mid.hip only where the latter
+// needs two passes over W (> 192 rows: SwiGLU 35 vs 46 us at 256 rows; 35 vs 25 us at 128), and loses to the
+// K-sliced rows kernel everywhere (QKV' 33 vs 16 us, mlp' 80 vs 27 us at 256 rows: 32..42 blocks walking
+// K sequentially cannot keep enough bytes in flight) — so the chain mode is off unless asked for.
+int g_dt_min_rows = 193;       // fused-epilogue decode GEMMs from this many rows on (dh_set_tuning key 6)
+int g_chain_min_rows = 1 << 30;  // partial-sum GEMMs from this many rows on (dh_set_tuning key 7); tests use 65
+
+// x·[w; w_ext]^T summed over the K-slices of `kps` k-steps in slice order: fp32 [M][n_main + n_ext]
+int dh_chain_tiled(const bf16_t* x, const bf16_t* w, const bf16_t* w_ext, float* y32, int M, int n_main, int n_ext, int K,
+                   int kps, hipStream_t s) {
+    DtArgs a{x, w, w_ext ? w_ext : w, y32, nullptr, nullptr, nullptr, M, n_main + n_ext, K, n_main, kps};
+    return launch_dt<0>(a, s);
+}
+
+bool dh_linear_dt_ok(const GemmArgs& a, int epilogue, int seg) {
+    return a.M >= g_dt_min_rows && a.K % BKD == 0 && seg > 0 && seg % 2 == 0 && (a.K / 32) % seg == 0 && a.N % 4 == 0 &&
+           (epilogue == DH_EPI_PLAIN || epilogue == DH_EPI_SWIGLU || epilogue == DH_EPI_ADAPTER);
+}
+
+int dh_linear_dt(const GemmArgs& g, int epilogue, int seg, hipStream_t s) {
+    DtArgs a{g.x, g.w, g.w2, g.y, g.vec_a, g.vec_b, g.resid, g.M, g.N, g.K, g.N, seg};
+    switch (epilogue) {
+        case DH_EPI_SWIGLU: return launch_dt<1>(a, s);
+        case DH_EPI_ADAPTER: return launch_dt<2>(a, s);
+        case DH_EPI_PLAIN: return launch_dt<3>(a, s);
+    }
+    dh_set_error("dh_linear_dt: unsupported epilogue %d", epilogue);
+    return 1;
+}

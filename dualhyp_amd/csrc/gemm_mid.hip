@@ -3,7 +3,7 @@
 // ONCE per block in LDS and shared by the 8 waves instead of being fetched per wave from L2 as
 // gemm_skinny.hip does.
 //   block : 640 threads = 8 compute waves (RS row sets x KQ K-parts) + 2 loader waves; a compute wave owns 16 W rows (SWIGLU: of fc_1
-//           AND fc_2) and KSL/KQ of the 4 k-steps of every slice, so a block covers only 16*RS output
+//           AND fc_2) and one contiguous K-part; a slice holds KSL/KQ k-steps of EVERY part, so a block covers only 16*RS output
 //           columns and even N = 5632 puts 176 blocks on the chip (SWIGLU: RS 2 x KQ 4, else 4 x 2)
 //   W     : global -> VGPR, ring of 8 slices per wave: 14 KiB in flight per wave, 112 KiB per block
 //   x     : rows [m0, m0 + 32*NG) x 128 k per slice, global -> LDS directly (global_load_lds, 16 B per
@@ -15,8 +15,8 @@
 //   reduce: the KQ partial accumulators meet in LDS (the x buffers are free by then); output tile pair t is
 //           summed in K-part order and finished by wave t % KQ of its row set
 //   grid  : (N / (16*RS), ceil(M / (32*NG)))
-// The summation order of an output is fixed by K alone (KQ interleaved chains, k ascending in each),
-// whatever M and NG: a row's result does not depend on how many other rows ride along (batch
+// The summation order of an output is fixed by K alone — KQ chains over CONTIGUOUS K-parts (k ascending in
+// each), added in part order; gemm_dt.hip reproduces exactly this order for > 64 rows — whatever M and NG: a row's result does not depend on how many other rows ride along (batch
 // invariance, same contract as the other decode kernels).
 #include "common.h"
 #include "gemm.h"
@@ -52,6 +52,7 @@ __global__ __launch_bounds__(640) void gemm_mid_kernel(GemmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y * (NG * 32);
     const int nsl = a.K / (KSL * 32);                     // K % 128 == 0 (checked on the host)
+    const int kpart = a.K / 32 / KQ;                      // k-steps per K-part: part q owns k-steps [q*kpart, (q+1)*kpart)
 
     if (wave >= 8) {
         // ---- loader waves: x slices global -> LDS, XD slices ahead of the MFMAs.  vmcnt is an in-order
@@ -64,10 +65,12 @@ __global__ __launch_bounds__(640) void gemm_mid_kernel(GemmArgs a) {
             const int row = 4 * (ldr + 2 * i) + (lane >> 4);
             int m = m0 + row;
             m = m < a.M ? m : a.M - 1;
-            xsrc[i] = a.x + (size_t)m * a.K + ((lane & 15) ^ (row & 15)) * 8;
+            // logical chunk lc of a slice row = k-step (lc / 4) of the slice: K-part (lc/4) / KPW, its step (lc/4) % KPW
+            const int lc = (lane & 15) ^ (row & 15);
+            xsrc[i] = a.x + (size_t)m * a.K + (((lc >> 2) / KPW) * kpart + (lc >> 2) % KPW) * 32 + (lc & 3) * 8;
         }
         auto load_x = [&](int s) __attribute__((always_inline)) {
-            const int ko = s < nsl ? s * (KSL * 32) : 0;       // past K: L2 hits that keep the count uniform
+            const int ko = s < nsl ? s * (KPW * 32) : 0;       // past K: L2 hits that keep the count uniform
             char* xb = smem + (s % NBUF) * XBUF;
 #pragma unroll
             for (int i = 0; i < NXL; ++i) glds16(xsrc[i] + ko, xb + (ldr + 2 * i) * (4 * XROW));
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(640) void gemm_mid_kernel(GemmArgs a) {
     auto load_w = [&](bf16x8 (&wf)[NM][KPW], int s) __attribute__((always_inline)) {
 #pragma unroll
         for (int c = 0; c < KPW; ++c) {
-            const int ko = (s * KSL + kq * KPW + c) * 32;
+            const int ko = (kq * kpart + s * KPW + c) * 32;
             wf[0][c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(w1 + ko));
             if (SW) wf[NM - 1][c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(w2 + ko));
         }
@@ -234,6 +237,9 @@ bool dh_linear_mid_ok(const GemmArgs& a, int epilogue) {
 }
 
 int dh_linear_mid(const GemmArgs& a, int epilogue, hipStream_t s) {
+    // > 64 rows: the tiled kernel runs the same K-part chains (gemm_dt.hip)
+    const int seg = a.K / 32 / (epilogue == DH_EPI_SWIGLU ? MidShape<DH_EPI_SWIGLU>::KQ : MidShape<DH_EPI_PLAIN>::KQ);
+    if (dh_linear_dt_ok(a, epilogue, seg)) return dh_linear_dt(a, epilogue, seg, s);
     switch (epilogue) {
         case DH_EPI_PLAIN: return launch_ng<DH_EPI_PLAIN>(a, s);
         case DH_EPI_SWIGLU: return launch_ng<DH_EPI_SWIGLU>(a, s);

@@ -402,6 +402,24 @@ extern "C" int dh_linear_partial_bf16(const dh_bf16* x, const dh_bf16* w, const 
     return 0;
 }
 
+// the rows kernel's K-slices (kps 8 or 16) are contiguous chains, so their ordered sum can also be
+// produced by the tiled kernel in one launch (n_part = 1 for the consumers)
+bool dh_chain_ok(int M, int n_main, int n_ext, int K, int ksplit) {
+    const int nks = K / 32, kps = (nks + ksplit - 1) / ksplit, N = n_main + n_ext;
+    return g_skinny_variant == 1 && M >= g_chain_min_rows && K % 64 == 0 && (kps == 8 || kps == 16) && (ksplit - 1) * kps < nks &&
+           N % 4 == 0 && n_main % ROWS == 0 && n_ext % ROWS == 0;
+}
+
+extern "C" int dh_linear_chain_bf16(const dh_bf16* x, const dh_bf16* w, const dh_bf16* w_ext, float* y32, int M, int n_main,
+                                    int n_ext, int K, int ksplit, void* stream) {
+    DH_CHECK(x && w && y32 && M >= 1 && ksplit >= 1 && (n_ext == 0 || w_ext), "dh_linear_chain_bf16: bad argument");
+    DH_CHECK(dh_chain_ok(M, n_main, n_ext, K, ksplit),
+             "dh_linear_chain_bf16: unsupported shape M=%d N=%d+%d K=%d ksplit=%d (needs >= %d rows, K %% 64 == 0, K-slices of 8 or 16 k-steps)",
+             M, n_main, n_ext, K, ksplit, g_chain_min_rows);
+    const int kps = (K / 32 + ksplit - 1) / ksplit;
+    return dh_chain_tiled(x, w, w_ext, y32, M, n_main, n_ext, K, kps, (hipStream_t)stream);
+}
+
 extern "C" int dh_set_tuning(int key, int value) {
     if (key == 0) { g_skinny_variant = value; return 0; }
     if (key == 1) { g_gemm_variant = value; return 0; }
@@ -409,6 +427,8 @@ extern "C" int dh_set_tuning(int key, int value) {
     if (key == 3) { g_mid = value; return 0; }
     if (key == 4) { g_linear_phase = value; return 0; }
     if (key == 5 && value >= 0) { g_gemm_gm = value; return 0; }
+    if (key == 6 && value >= 1) { g_dt_min_rows = value; return 0; }
+    if (key == 7 && value >= 1) { g_chain_min_rows = value; return 0; }
     dh_set_error("dh_set_tuning: unknown key %d", key);
     return 1;
 }

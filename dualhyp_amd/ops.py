@@ -175,6 +175,17 @@ def linear_partial(x: torch.Tensor, w: torch.Tensor, w_ext: Optional[torch.Tenso
     return y
 
 
+def linear_chain(x: torch.Tensor, w: torch.Tensor, w_ext: Optional[torch.Tensor] = None, ksplit: int = 1) -> torch.Tensor:
+    """fp32 [M, n_main+n_ext]: the ksplit partials of `linear_partial` added in slice order (M >= 65); dh_linear_chain_bf16."""
+    x, w = _dev(x, name="x"), _dev(w, name="w")
+    K = x.size(-1)
+    M = x.numel() // K
+    n_ext = 0 if w_ext is None else _dev(w_ext, name="w_ext").size(0)
+    y = torch.empty((M, w.size(0) + n_ext), dtype=torch.float32, device=x.device)
+    check(_lib.load().dh_linear_chain_bf16(_p(x), _p(w), _p(w_ext), _p(y), M, w.size(0), n_ext, K, ksplit, _stream()))
+    return y
+
+
 def finish_norm(h32: torch.Tensor, d: int, x_resid: torch.Tensor, w_norm: torch.Tensor, eps: float,
                 lora_b: Optional[torch.Tensor] = None, lora_scale: float = 1.0,
                 row_tail: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -170,6 +170,55 @@ def test_linear_partial_wide_rows(dev, M, N, n_ext, K, ks):
     ref = x.float() @ torch.cat([W, A]).float().T if n_ext else x.float() @ W.float().T
     got = wide.sum(0)
     assert (got - ref).abs().max().item() <= 1e-3 * ref.abs().max().item() + 1e-4
+    # the tiled kernel (gemm_dt.hip) delivers the partials already added, in slice order, bit for bit
+    if M >= 65 and K % 64 == 0 and (K // 32 + ks - 1) // ks in (8, 16):
+        seq = wide[0].clone()
+        for p in range(1, ks):
+            seq = seq + wide[p]
+        from dualhyp_amd import _lib
+        _lib.load().dh_set_tuning(7, 65)
+        try:
+            chain = ops.linear_chain(x, W, A, ksplit=ks)
+        finally:
+            _lib.load().dh_set_tuning(7, 1 << 30)
+        assert torch.equal(chain, seq), "tiled chain sum differs from the ordered sum of the streamed partials"
+    else:
+        with pytest.raises(Exception):
+            ops.linear_chain(x, W, A, ksplit=ks)
+
+
+@pytest.mark.parametrize("d,I,V", [(2048, 5632, 32000), (256, 384, 256), (512, 768, 512)])
+def test_decode_phase_linear_rows_invariant(dev, d, I, V):
+    """Decode-phase GEMMs with fused epilogues: <= 64 rows stream the weights (gemm_mid.hip), more rows take
+    the tiled kernel (gemm_dt.hip) — every row comes out bit-identical either way."""
+    from dualhyp_amd import ops, _lib
+    lib = _lib.load()
+    M = 200
+    x = U((M, d), 1.0, f"ix{d}").to(dev)
+    w1, w2 = U((I, d), 0.05, f"i1{d}").to(dev), U((I, d), 0.05, f"i2{d}").to(dev)
+    wl = U((V, d), 0.05, f"il{d}").to(dev)
+    sc, bi = (1 + U((V,), 0.5, "isc").float()).bfloat16().to(dev), U((V,), 0.5, "ibi").to(dev)
+    act = U((M, I), 1.0, f"ia{d}").to(dev)
+    wp, res = U((d, I), 0.05, f"ip{d}").to(dev), U((M, d), 1.0, f"ir{d}").to(dev)
+    calls = {
+        "swiglu": lambda xs, sl: ops.linear(xs, w1, epilogue=ops.EPI_SWIGLU, w2=w2),
+        "adapter": lambda xs, sl: ops.linear(xs, wl, epilogue=ops.EPI_ADAPTER, scale=sc, bias=bi),
+        "plain+resid": lambda xs, sl: ops.linear(act[sl].contiguous(), wp, resid=res[sl].contiguous()),
+    }
+    lib.dh_set_tuning(4, 2)          # public dh_linear_bf16 in the decode phase
+    lib.dh_set_tuning(6, 65)         # tiled kernel from 65 rows on (default 193)
+    try:
+        for name, fn in calls.items():
+            whole = fn(x, slice(0, M))
+            for a in (0, 64, 150):
+                sl = slice(a, min(a + 32, M))
+                part = fn(x[sl].contiguous(), sl)
+                assert torch.equal(part, whole[sl]), f"{name}: rows {a}.. differ between the tiled and the streaming kernel"
+            sl = slice(100, 164)     # 64 rows: still the streaming kernel, two row groups
+            assert torch.equal(fn(x[sl].contiguous(), sl), whole[sl]), name
+    finally:
+        lib.dh_set_tuning(4, 0)
+        lib.dh_set_tuning(6, 193)
 
 
 def _attn_setup(dev, hs, n_head, n_groups, lens, pos0, s_max, seed):
