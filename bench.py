@@ -197,14 +197,16 @@ def cpu_baseline(cfg, prompt, new_tokens: int) -> dict:
     sd = synth_state_dict(cfg, seed=1337, device="cpu")
     m = O.OracleGPT(cfg, sd)
     T = prompt.numel()
-    t0 = time.perf_counter()
-    ids = O.generate(m, prompt.cpu(), T + new_tokens, temperature=0.2, top_k=1, eos_id=None, mode="argmax")
-    dt = time.perf_counter() - t0
-    assert ids.numel() == T + new_tokens
+    n, t0 = 0, time.perf_counter()
+    while n < 8 and time.perf_counter() - t0 < 10.0:      # ~10-15 s of CPU work
+        ids = O.generate(m, prompt.cpu(), T + new_tokens, temperature=0.2, top_k=1, eos_id=None, mode="argmax")
+        assert ids.numel() == T + new_tokens
+        n += 1
+    dt = (time.perf_counter() - t0) / n
     return {"value": 1.0 / dt, "unit": "utterances/s",
             "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 utterance, {T}-token prompt -> {new_tokens} generated tokens, batch 1, bf16, "
-                      f"{torch.get_num_threads()} threads ({dt:.1f} s)"}
+            "sample": f"{n} utterances one after the other, {T}-token prompt -> {new_tokens} generated tokens, batch 1 "
+                      f"(as the reference runs), bf16, {torch.get_num_threads()} threads ({dt:.1f} s each)"}
 
 
 if __name__ == "__main__":
