@@ -59,6 +59,8 @@ SIGNATURES = {
     "dh_engine_create": (I, [C.POINTER(ModelDesc), I, I, I, C.POINTER(P)]),
     "dh_engine_destroy": (None, [P]),
     "dh_engine_device_bytes": (I64, [P]),
+    "dh_im2col3_bf16": (I, [P, P, I, I, I, I, I, P]),
+    "dh_pool_head_bf16": (I, [P, P, P, P, I, I, I, I, P]),
     "dh_cross_entropy_fwd": (I, [P, I, P, P, P, I, I, P]),
     "dh_cross_entropy_bwd": (I, [P, I, P, P, P, P, I, I, P]),
     "dh_engine_forward": (I, [P, P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), I, P, P, P]),

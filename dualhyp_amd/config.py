@@ -61,6 +61,10 @@ class Config:
     to_mlp: bool = False
     to_head: bool = False
     lora_start_layer: int = 0
+    # RelPrompt reliability predictors (ger/relprompt.py Config): encoder feature widths and chunk pooling
+    whisper_dim: int = 1280
+    raven_dim: int = 1024
+    pool_size: int = 10
 
     def __post_init__(self) -> None:
         if not self.name:

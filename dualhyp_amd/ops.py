@@ -140,6 +140,25 @@ def sample(logits: torch.Tensor, tokens: torch.Tensor, length: torch.Tensor, don
                                      int(seed) & ((1 << 64) - 1), int(step), _stream()))
 
 
+def im2col3(x: torch.Tensor, ld: int, relu: bool = False) -> torch.Tensor:
+    """[B*T, ld] im2col matrix of a k=3, pad=1 convolution over x [B,T,C] with a ones column at 3C; dh_im2col3_bf16."""
+    x = _dev(x, name="x")
+    B, T, Cc = x.shape
+    out = torch.empty((B * T, ld), dtype=torch.bfloat16, device=x.device)
+    check(_lib.load().dh_im2col3_bf16(_p(x), _p(out), B, T, Cc, ld, int(relu), _stream()))
+    return out
+
+
+def pool_head(h: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, pool: int) -> torch.Tensor:
+    """ReLU -> AvgPool1d(pool, ceil) -> Linear(H, 3) on h [B,T,H]; dh_pool_head_bf16."""
+    h = _dev(h, name="h")
+    B, T, H = h.shape
+    out = torch.empty((B, (T + pool - 1) // pool, 3), dtype=torch.bfloat16, device=h.device)
+    check(_lib.load().dh_pool_head_bf16(_p(h), _p(_dev(w, name="w")), _p(_dev(bias, name="bias")), _p(out), B, T, H, int(pool),
+                                        _stream()))
+    return out
+
+
 def cross_entropy_fwd(logits: torch.Tensor, targets: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """(loss_per_row fp32 [rows], lse fp32 [rows]); ignored rows (target -1) give 0; dh_cross_entropy_fwd."""
     assert logits.dtype in (torch.bfloat16, torch.float32), f"logits must be bf16 or fp32, got {logits.dtype}"

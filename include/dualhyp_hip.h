@@ -197,6 +197,16 @@ int dh_cross_entropy_fwd(const void* logits, int is_f32, const int64_t* targets,
 int dh_cross_entropy_bwd(const void* logits, int is_f32, const int64_t* targets, const float* lse,
                          const float* grad_row, void* dlogits, int rows, int vocab, void* stream);
 
+/* RelPrompt reliability predictor — ger/relprompt.py:126-147 (NoiseMaskClassifier).  The two k=3 convolutions
+ * are dh_linear_bf16 over the matrix built here: out [B*T, ld] with out[b,t, dk*C + c] = x[b, t+dk-1, c]
+ * (zero outside the sequence, through ReLU if relu != 0), a column of ones at 3C (the bias rides the fp32
+ * accumulation as the weight's column 3C) and zero padding up to ld (multiple of 64 for the GEMM). */
+int dh_im2col3_bf16(const dh_bf16* x, dh_bf16* out, int B, int T, int C, int ld, int relu, void* stream);
+/* ReLU -> AvgPool1d(pool, stride pool, ceil_mode: a short last window averages its own elements) ->
+ * Linear(H -> 3): h [B,T,H] pre-activation, w [3,H], bias [3], out [B, ceil(T/pool), 3]. */
+int dh_pool_head_bf16(const dh_bf16* h, const dh_bf16* w, const dh_bf16* bias, dh_bf16* out, int B, int T,
+                      int H, int pool, void* stream);
+
 /* One decode-loop tail per sequence — generate/base.py:62-80:
  *   l = logits/temperature (bf16) ; keep l >= k-th largest ; softmax ; multinomial.
  * top_k == 1 is resolved as arg-max with the LOWEST index among equal maxima (the reference

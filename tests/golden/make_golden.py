@@ -380,6 +380,28 @@ def gen_convert(rlora) -> None:
     save("convert_hf_llama", tensors, {"config": {k: v for k, v in kw.items()}, "shard2_keys": sorted(late)})
 
 
+def gen_classifier() -> None:
+    """ger/relprompt.py NoiseMaskClassifier (eval mode) on seeded features, bf16 and fp32: both encoder
+    widths / pool sizes the reference instantiates, T not a multiple of the pool (ceil-mode tail)."""
+    import ger.relprompt as rp
+    from dualhyp_amd.synth import uniform, stream_id
+    tensors, meta = {}, {}
+    for tag, (C, pool, T) in {"audio": (1280, 20, 173), "visual": (1024, 10, 87)}.items():
+        m = rp.NoiseMaskClassifier(C, pool_size=pool).eval()
+        sd = {k: uniform(tuple(v.shape), 1.0 / math.sqrt(v[0].numel() if v.dim() > 1 else 256.0), stream_id(77, tag + k)).float()
+              for k, v in m.state_dict().items()}
+        m.load_state_dict(sd)
+        x = uniform((2, T, C), 1.5, stream_id(77, tag + "x")).float()
+        with torch.no_grad():
+            y32 = m(x)
+            yb = m.to(torch.bfloat16)(x.to(torch.bfloat16))
+        # weights and features are regenerated from the hash by the tests (seed 77, stream names tag+key / tag+"x")
+        tensors[f"{tag}.logits_fp32"], tensors[f"{tag}.logits_bf16"] = y32, yb
+        meta[tag] = {"C": C, "pool": pool, "T": T, "seed": 77,
+                     "shapes": {k: list(v.shape) for k, v in sd.items()}}
+    save("noise_mask_classifier", tensors, meta)
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-full", action="store_true")
@@ -390,6 +412,8 @@ def main() -> None:
     want = lambda k: (not a.only) or a.only == k
     if want("misc"):
         gen_misc(rutils, rprompts)
+    if want("classifier"):
+        gen_classifier()
     if want("convert"):
         gen_convert(rlora)
     if want("tiny"):

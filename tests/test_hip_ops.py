@@ -425,3 +425,28 @@ def test_sampling_topk_distribution(dev):
     p = torch.softmax(torch.tensor([2.0, 1.5, 1.0, 0.5, 0.0]), 0)
     freq = torch.tensor([(picks == t).float().mean() for t in (3, 50, 400, 800, 999)])
     assert (freq - p).abs().max() < 0.03, (freq, p)
+
+
+def test_noise_mask_classifier(dev):
+    """RelPrompt reliability predictor on the HIP path vs the reference module's own outputs
+    (tests/golden/noise_mask_classifier: ger/relprompt.py:126-147 run on the CPU, bf16 and fp32)."""
+    from conftest import load_golden
+    from dualhyp_amd.relprompt import NoiseMaskClassifier
+    from dualhyp_amd.synth import uniform, stream_id
+    t, meta = load_golden("noise_mask_classifier")
+    for tag, mt in meta.items():
+        C, pool, T = mt["C"], mt["pool"], mt["T"]
+        m = NoiseMaskClassifier(C, pool_size=pool).eval()
+        sd = {k: uniform(tuple(shape), 1.0 / math.sqrt(math.prod(shape[1:]) if len(shape) > 1 else 256.0), stream_id(mt["seed"], tag + k)).float()
+              for k, shape in mt["shapes"].items()}
+        m.load_state_dict(sd)
+        m = m.to(dev)
+        x = uniform((2, T, C), 1.5, stream_id(mt["seed"], tag + "x")).to(dev)
+        got = m(x).float().cpu()
+        want_b, want_f = t[f"{tag}.logits_bf16"].float(), t[f"{tag}.logits_fp32"]
+        assert got.shape == want_f.shape == (2, (T + pool - 1) // pool, 3)
+        e_hip, e_ref = (got - want_f).abs().max().item(), (want_b - want_f).abs().max().item()
+        print(f"[parity] classifier {tag}: |hip-fp32|max {e_hip:.3e} vs |ref_bf16-fp32|max {e_ref:.3e}; "
+              f"bit-exact vs ref bf16 {(got == want_b).float().mean().item():.1%}")
+        assert e_hip <= 1.5 * e_ref + 1e-3
+        assert torch.equal(got.argmax(-1), want_f.argmax(-1)) or (got - want_f).abs().max() < 0.02
