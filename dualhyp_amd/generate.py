@@ -40,9 +40,12 @@ def generate_batch(model: GPT, prompts: Sequence[torch.Tensor], max_new_tokens: 
     chunks = [(c, min(c + prefill_batch, B)) for c in range(0, B, prefill_batch)]
     eng = model.engine(B, need_pos, max(sum(lens[a:b]) for a, b in chunks))
     tok_ld = T_max + max_new_tokens
-    tokens = torch.zeros((B, tok_ld), dtype=torch.int64, device=dev)
-    for i, p in enumerate(prompts):
-        tokens[i, : lens[i]] = p.to(dev)
+    if min(lens) == T_max:             # equal lengths: one copy
+        tokens = torch.nn.functional.pad(torch.stack([p.to(dev) for p in prompts]), (0, tok_ld - T_max))
+    else:                              # ragged: right-pad with 0 (pad_sequence), then out to the buffer width
+        tokens = torch.nn.utils.rnn.pad_sequence([p.to(dev) for p in prompts], batch_first=True)
+        tokens = torch.nn.functional.pad(tokens, (0, tok_ld - tokens.size(1)))
+    tokens = tokens.contiguous()
     length = torch.tensor(lens, dtype=torch.int32, device=dev)
     done = torch.zeros(B, dtype=torch.int32, device=dev)
     eng.set_rsqrt_emulation(model.cpu_rsqrt_vec_width, whole_call=False)   # B independent batch-1 runs
