@@ -59,7 +59,9 @@ def main() -> None:
     ap.add_argument("--schedule", choices=("merged", "threads"), default="merged",
                     help="merged: one engine, chunked prefill + joint decode (generate_batch); threads: one engine, "
                          "HIP stream and host thread per in-flight batch (dualhyp_amd.pipeline)")
+    ap.add_argument("--engines", type=int, default=2, help="--schedule threads: engines (each decodes --in-flight batches jointly)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap-probe", action="store_true")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -123,12 +125,12 @@ def main() -> None:
         run_merged(batches[:n_warm])
         engs = [model.engine()]
     else:
-        # `in-flight` engines: each has its own KV cache, workspace, decode graph and HIP stream and
-        # shares the one copy of the weights
-        pipe = BatchPipeline(model, G, B, PROMPT_LEN + NEW_TOKENS, B * PROMPT_LEN)
-        pipe.warm(batches[0], NEW_TOKENS, **gen_kw)   # every engine: alloc + graph capture
-        for f in [pipe.submit(batches[i], NEW_TOKENS, **gen_kw) for i in range(1, n_warm)]:
-            f.result()
+        # `engines` engines, each with its own KV cache, workspace, decode graph, HIP stream and host thread,
+        # sharing one copy of the weights; each takes groups of G batches (chunked prefill + joint decode), so
+        # one engine's latency-bound decode loop overlaps the other's prefills
+        pipe = BatchPipeline(model, a.engines, B * G, PROMPT_LEN + NEW_TOKENS, B * PROMPT_LEN)
+        flat = lambda bs: [p for b in bs for p in b]
+        pipe.warm(flat([batches[0]] * min(G, a.steps)), NEW_TOKENS, prefill_batch=B, **gen_kw)
         engs = [m.engine() for m in pipe.models]
     for e in engs:
         e.set_timing(True)
@@ -137,7 +139,9 @@ def main() -> None:
     if a.schedule == "merged":
         outs = run_merged(batches[n_warm:])
     else:
-        outs = [f.result() for f in [pipe.submit(b, NEW_TOKENS, **gen_kw) for b in batches[n_warm:]]]
+        timed = batches[n_warm:]
+        futs = [pipe.submit(flat(timed[g:g + G]), NEW_TOKENS, prefill_batch=B, **gen_kw) for g in range(0, len(timed), G)]
+        outs = [o[i:i + B] for f in futs for o in [f.result()] for i in range(0, len(o), B)]
     barrier()
     dt = time.perf_counter() - t0
     gemm_ms = gemm_n = attn_ms = 0
@@ -179,6 +183,23 @@ def main() -> None:
                          "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
                          "prefill_attention_ms_per_step": attn_ms / max(a.steps, 1)},
         }
+    if rank == 0 and world == 1 and a.schedule == "merged" and not a.no_overlap_probe:
+        # informational, outside the timed region of `value`: two engines on two HIP streams, each decoding G
+        # batches jointly, so one engine's latency-bound decode loop runs under the other's prefills.  Higher
+        # throughput, but the concurrent kernels time-slice the CUs and every per-kernel duration (hence a
+        # roofline measured there) is inflated — which is why it is not the default schedule.
+        pipe = BatchPipeline(model, 2, B * G, PROMPT_LEN + NEW_TOKENS, B * PROMPT_LEN)
+        flat = lambda bs: [p for b in bs for p in b]
+        pipe.warm(flat([batches[0]] * G), NEW_TOKENS, prefill_batch=B, **gen_kw)
+        reps = [batches[i % n_batches] for i in range(2 * G)]
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for f in [pipe.submit(flat(reps[g:g + G]), NEW_TOKENS, prefill_batch=B, **gen_kw) for g in range(0, len(reps), G)]:
+            f.result()
+        torch.cuda.synchronize()
+        result["overlap_probe"] = {"schedule": "threads, 2 engines x %d batches each" % G, "steps": len(reps),
+                                   "value": B * len(reps) / (time.perf_counter() - t1), "unit": "utterances/s"}
+        pipe.close()
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(cfg, corpus[0], NEW_TOKENS)
     if rank == 0:
