@@ -50,10 +50,10 @@ def gemm_flops_per_prefill(cfg, n_tok: int, n_seq: int) -> float:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--in-flight", type=int, default=8,
+    ap.add_argument("--in-flight", type=int, default=32,
                     help="batches (steps) decoded together per GPU: each batch of --batch prompts is prefilled on its "
                          "own, then the decode loop runs over all in-flight sequences at once")
     ap.add_argument("--schedule", choices=("merged", "threads"), default="merged",
@@ -108,12 +108,14 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    phase = {}     # HIP-event time of the prefill and decode phases of the merged schedule (timed region only)
+
     def run_merged(bs):
         """a "step" is ONE batch of B utterances; up to G consecutive steps share a decode loop"""
         outs = []
         for g in range(0, len(bs), G):
             flat = [p for b in bs[g:g + G] for p in b]
-            o = generate_batch(model, flat, NEW_TOKENS, prefill_batch=B, **gen_kw)
+            o = generate_batch(model, flat, NEW_TOKENS, prefill_batch=B, timing=phase, **gen_kw)
             outs += [o[i:i + B] for i in range(0, len(o), B)]
         return outs
 
@@ -134,6 +136,7 @@ def main() -> None:
         engs = [m.engine() for m in pipe.models]
     for e in engs:
         e.set_timing(True)
+    phase.clear()
     barrier()
     t0 = time.perf_counter()
     if a.schedule == "merged":
@@ -183,6 +186,17 @@ def main() -> None:
                          "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
                          "prefill_attention_ms_per_step": attn_ms / max(a.steps, 1)},
         }
+    if rank == 0 and phase.get("decode_steps"):
+        # second bound of the path: the decode step streams every weight once for all rows of the
+        # launch plus each sequence's KV prefix; algorithmic bytes per step = 2.078 GB + rows x 22,528 B x S (S ~ 544)
+        rows = phase["decode_row_steps"] / phase["decode_steps"]
+        step_ms = phase["decode_ms"] / phase["decode_steps"]
+        step_bytes = 2 * (968_884_224 + 65_536_000 + 4_505_600) + rows * 22_528 * (PROMPT_LEN + NEW_TOKENS / 2)
+        result["phases"] = {"prefill_ms_per_step": phase["prefill_ms"] / a.steps, "decode_ms_per_step": phase["decode_ms"] / a.steps,
+                            "decode_loop_ms_per_token": step_ms, "decode_rows_per_launch": rows}
+        result["roofline_decode"] = {"bound": "hbm", "achieved": step_bytes / (step_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                     "frac": step_bytes / (step_ms * 1e-3) / 1e9 / 8000.0,
+                                     "bytes_per_decode_step": step_bytes, "kernel": "decode step (157 launches: streaming GEMMs + fused attention)"}
     if rank == 0 and world == 1 and a.schedule == "merged" and not a.no_overlap_probe:
         # informational, outside the timed region of `value`: two engines on two HIP streams, each decoding G
         # batches jointly, so one engine's latency-bound decode loop runs under the other's prefills.  Higher

@@ -21,7 +21,7 @@ struct Timing {
 
 }  // namespace
 
-constexpr int MAX_DECODE_ROWS = 256;   // single-token calls up to here take the 7-launch streaming path
+constexpr int MAX_DECODE_ROWS = 2048;  // single-token calls up to here take the 7-launch streaming path
 
 struct dh_engine {
     dh_model_desc d;

@@ -232,7 +232,7 @@ int launch_ng(const GemmArgs& a, hipStream_t s) {
 int g_mid = 1;
 
 bool dh_linear_mid_ok(const GemmArgs& a, int epilogue) {
-    return g_mid != 0 && a.K % (KSL * 32) == 0 && a.N % 16 == 0 && a.M <= 256 &&
+    return g_mid != 0 && a.K % (KSL * 32) == 0 && a.N % 16 == 0 && a.M <= 4096 &&
            (epilogue == DH_EPI_PLAIN || epilogue == DH_EPI_SWIGLU || epilogue == DH_EPI_ADAPTER);
 }
 

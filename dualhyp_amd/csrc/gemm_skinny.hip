@@ -377,7 +377,7 @@ int launch(const GemmArgs& a, hipStream_t s) {
 
 extern "C" int dh_linear_partial_bf16(const dh_bf16* x, const dh_bf16* w, const dh_bf16* w_ext, float* y32, int M,
                                       int n_main, int n_ext, int K, int ksplit, void* stream) {
-    DH_CHECK(x && w && y32 && M >= 1 && M <= 256, "dh_linear_partial_bf16: need 1 <= M <= 256 (got %d)", M);
+    DH_CHECK(x && w && y32 && M >= 1 && M <= 4096, "dh_linear_partial_bf16: need 1 <= M <= 4096 (got %d)", M);
     DH_CHECK(K % 32 == 0 && n_main % ROWS == 0 && n_ext % ROWS == 0 && n_main > 0 && n_ext >= 0,
              "dh_linear_partial_bf16: K %% 32 and row counts %% 16 must be 0");
     DH_CHECK(n_ext == 0 || w_ext, "dh_linear_partial_bf16: null w_ext");

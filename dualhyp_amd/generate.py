@@ -19,7 +19,7 @@ from .gpt import GPT
 @torch.inference_mode()
 def generate_batch(model: GPT, prompts: Sequence[torch.Tensor], max_new_tokens: int, *, temperature: float = 1.0,
                    top_k: Optional[int] = None, eos_id: Optional[int] = None, seed: int = 1337,
-                   return_state: bool = False, prefill_batch: int = 32):
+                   return_state: bool = False, prefill_batch: int = 32, timing: Optional[dict] = None):
     """prompts: 1-D int64 tensors (any lengths).  Returns a list of 1-D tensors prompt+generated,
     cut before the EOS token when one was produced.
 
@@ -49,16 +49,28 @@ def generate_batch(model: GPT, prompts: Sequence[torch.Tensor], max_new_tokens: 
     length = torch.tensor(lens, dtype=torch.int32, device=dev)
     done = torch.zeros(B, dtype=torch.int32, device=dev)
     eng.set_rsqrt_emulation(model.cpu_rsqrt_vec_width, whole_call=False)   # B independent batch-1 runs
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if timing is not None else None
+    if ev:
+        ev[0].record()
     last = torch.empty((B, eng.vocab), dtype=torch.bfloat16, device=dev)
     for a, b in chunks:
         packed = torch.cat([p.to(dev).reshape(-1) for p in prompts[a:b]])
         _, last[a:b] = eng.forward(packed, lens[a:b], [0] * (b - a), want_all=False, want_last=True, slot_base=a)
     ops.sample(last, tokens, length, done, temperature=temperature, top_k=top_k, eos_id=eos_id, seed=seed, step=0)
+    if ev:
+        ev[1].record()
     if max_new_tokens > 1:
         eng.decode(tokens, length, done, max_new_tokens - 1, temperature, top_k, eos_id, seed, first_step=0)
+    if ev:
+        ev[2].record()
     model._cache_len = []  # slots now hold these sequences; a later cached forward must start at 0
     length_h = length.tolist()          # the one host read-back
     done_h = done.tolist()
+    if ev:   # the read-back above has synchronised the stream
+        timing["prefill_ms"] = timing.get("prefill_ms", 0.0) + ev[0].elapsed_time(ev[1])
+        timing["decode_ms"] = timing.get("decode_ms", 0.0) + ev[1].elapsed_time(ev[2])
+        timing["decode_steps"] = timing.get("decode_steps", 0) + max_new_tokens - 1
+        timing["decode_row_steps"] = timing.get("decode_row_steps", 0) + B * (max_new_tokens - 1)
     out: List[torch.Tensor] = []
     for i in range(B):
         n = min(length_h[i], lens[i] + max_new_tokens)
