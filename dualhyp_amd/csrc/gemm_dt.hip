@@ -20,12 +20,13 @@
 #include "common.h"
 #include "gemm.h"
 
+int g_dt_stages = 0;   // 0: by grid size, else 2 or 4 (dh_set_tuning key 8)
+
 namespace {
 
 constexpr int TB = 128;                 // block tile edge (rows of x, rows of W)
 constexpr int BKD = 64;                 // K per stage (two k-steps of 32)
 constexpr int STAGE = 2 * TB * BKD * 2; // bytes per stage: W tile 16 KiB + x tile 16 KiB
-constexpr int NSTAGE = 4;                // ring: 3 stages in flight ahead of the one being multiplied
 
 __device__ __forceinline__ int swz7(int row) { return (row >> 1) & 7; }
 
@@ -40,7 +41,7 @@ struct DtArgs {
     int M, N, K, n_main, seg;   // seg: k-steps per chain segment (even)
 };
 
-template <int MODE>
+template <int MODE, int NSTAGE>   // NSTAGE 4: one block per CU, 3 stages in flight; NSTAGE 2: two blocks per CU
 __global__ __launch_bounds__(256) void gemm_dt_kernel(DtArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // NSTAGE stages
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -105,16 +106,18 @@ __global__ __launch_bounds__(256) void gemm_dt_kernel(DtArgs a) {
     const int nk = a.K / BKD;
     const int seg_kt = a.seg / 2;       // stages per chain segment
 
-    stage(0);
-    if (1 < nk) stage(1);
-    if (2 < nk) stage(2);
-    if (2 < nk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    // prologue: NSTAGE-1 stages requested, the first one waited for
+#pragma unroll
+    for (int p = 0; p < NSTAGE - 1; ++p)
+        if (p < nk) stage(p);
+    if (NSTAGE == 4 && 2 < nk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (NSTAGE == 4 && 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     int in_seg = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        // ring slot (kt+3) % 4 was last read in iteration kt-1, which ended with a barrier
-        if (kt + 3 < nk) stage(kt + 3);
+        // ring slot (kt+NSTAGE-1) % NSTAGE was last read in iteration kt-1, which ended with a barrier
+        if (kt + NSTAGE - 1 < nk) stage(kt + NSTAGE - 1);
         const char* sA = smem + (kt % NSTAGE) * STAGE;
         const char* sB = sA + STAGE / 2;
 #pragma unroll
@@ -142,9 +145,9 @@ __global__ __launch_bounds__(256) void gemm_dt_kernel(DtArgs a) {
                     cur[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
         }
-        // own share of stage kt+1 landed (stages kt+2, kt+3 may stay in flight), then everybody's
-        if (kt + 3 < nk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        // own share of stage kt+1 landed (later stages may stay in flight), then everybody's
+        if (NSTAGE == 4 && kt + 3 < nk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (NSTAGE == 4 && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
@@ -195,28 +198,41 @@ __global__ __launch_bounds__(256) void gemm_dt_kernel(DtArgs a) {
     }
 }
 
-template <int MODE>
-int launch_dt(const DtArgs& a, hipStream_t s) {
-    constexpr int lds = NSTAGE * STAGE;     // 128 KiB
+template <int MODE, int NSTAGE>
+int launch_dt_n(const DtArgs& a, int blocks, hipStream_t s) {
+    constexpr int lds = NSTAGE * STAGE;     // 128 KiB / 64 KiB
     static bool attr = false;
     if (!attr) {
-        DH_HIP(hipFuncSetAttribute((const void*)gemm_dt_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        DH_HIP(hipFuncSetAttribute((const void*)gemm_dt_kernel<MODE, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr = true;
     }
-    const int m_tiles = cdiv(a.M, TB), n_tiles = cdiv(a.N, MODE == 1 ? 64 : TB);
-    hipLaunchKernelGGL(gemm_dt_kernel<MODE>, dim3(m_tiles * n_tiles), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gemm_dt_kernel<MODE, NSTAGE>), dim3(blocks), dim3(256), lds, s, a);
     DH_LAUNCH_CHECK();
     return 0;
 }
 
+template <int MODE>
+int launch_dt(const DtArgs& a, hipStream_t s) {
+    const int m_tiles = cdiv(a.M, TB), n_tiles = cdiv(a.N, MODE == 1 ? 64 : TB);
+    const int blocks = m_tiles * n_tiles;
+    // more than one block per CU to go round: two co-resident blocks hide each other's waits better than
+    // a deeper ring in one block
+    const int stages = g_dt_stages ? g_dt_stages : (blocks > 256 ? 2 : 4);
+    return stages == 2 ? launch_dt_n<MODE, 2>(a, blocks, s) : launch_dt_n<MODE, 4>(a, blocks, s);
+}
+
 }  // namespace
 
-// Measured (tools/tune_dt.py, TinyLlama shapes): the tiled kernel beats gemm_mid.hip only where the latter
-// needs two passes over W (> 192 rows: SwiGLU 35 vs 46 us at 256 rows; 35 vs 25 us at 128), and loses to the
-// K-sliced rows kernel everywhere (QKV' 33 vs 16 us, mlp' 80 vs 27 us at 256 rows: 32..42 blocks walking
-// K sequentially cannot keep enough bytes in flight) — so the chain mode is off unless asked for.
+// Measured (tools/tune_dt.py, TinyLlama shapes, us):         rows  256    512   1024   2048
+//   SwiGLU   gemm_mid (two passes from 193 rows on)              46      -      -      -
+//            this kernel, 4 stages / 2 stages                   36/41  68/48 102/88 198/134
+//   QKV'     K-sliced rows kernel | this kernel (chain mode)    16|33  30|33  43|35  83|45
+//   mlp'     K-sliced rows kernel | this kernel (chain mode)    27|81  50|81  76|82 150|83
+// A block walks K sequentially (about 1 us per 64-wide stage however many stages are in flight), so the
+// chain mode costs a constant ~nk us until the m-tiles fill the chip, while K-slicing across blocks scales
+// with the rows: the crossover is near 768 rows.
 int g_dt_min_rows = 193;       // fused-epilogue decode GEMMs from this many rows on (dh_set_tuning key 6)
-int g_chain_min_rows = 1 << 30;  // partial-sum GEMMs from this many rows on (dh_set_tuning key 7); tests use 65
+int g_chain_min_rows = 768;    // partial-sum GEMMs from this many rows on (dh_set_tuning key 7)
 
 // x·[w; w_ext]^T summed over the K-slices of `kps` k-steps in slice order: fp32 [M][n_main + n_ext]
 int dh_chain_tiled(const bf16_t* x, const bf16_t* w, const bf16_t* w_ext, float* y32, int M, int n_main, int n_ext, int K,
