@@ -50,10 +50,10 @@ def gemm_flops_per_prefill(cfg, n_tok: int, n_seq: int) -> float:
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--in-flight", type=int, default=32,
+    ap.add_argument("--in-flight", type=int, default=64,
                     help="batches (steps) decoded together per GPU: each batch of --batch prompts is prefilled on its "
                          "own, then the decode loop runs over all in-flight sequences at once")
     ap.add_argument("--schedule", choices=("merged", "threads"), default="merged",
