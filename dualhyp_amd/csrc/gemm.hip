@@ -243,7 +243,10 @@ int dh_linear_impl(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N,
         (epilogue != DH_EPI_ADAPTER || (vec_a && vec_b)) && dh_linear_mid_ok(a, epilogue))
         return dh_linear_mid(a, epilogue, s);
     const bool skinny = (kernel == 0 || kernel == 2) && M <= 32 && K % 32 == 0;   // weight-streaming kernel (gemm_skinny.hip)
-    const bool big = !skinny && g_gemm_variant >= 1 && M >= 256 && N >= (epilogue == DH_EPI_SWIGLU ? 128 : 256);
+    // the 256-tile kernel runs one block per CU: below ~half a chip of tiles (a training micro-batch, M ~ 560)
+    // the 128-tile kernel puts four times the blocks in flight and wins
+    const int tiles256 = cdiv(M, 256) * cdiv(N, epilogue == DH_EPI_SWIGLU ? 128 : 256);
+    const bool big = !skinny && g_gemm_variant >= 1 && M >= 256 && N >= (epilogue == DH_EPI_SWIGLU ? 128 : 256) && tiles256 >= 128;
     if (big) {
         if (epilogue == DH_EPI_LORA) {
             DH_CHECK(xa && lora_b && xa_ld >= 16 && xa_ld % 8 == 0, "dh_linear_bf16: LORA epilogue needs xa/lora_b");

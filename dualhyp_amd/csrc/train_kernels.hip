@@ -155,6 +155,50 @@ __global__ __launch_bounds__(256) void tn_accum_kernel(const bf16_t* __restrict_
     }
 }
 
+// The LoRA shapes have one LARGE output dimension (d, or the fused qkv width) and one small one (the
+// rank, padded to 16 or 3 x 16): lanes run along the large one (coalesced loads of its operand, coalesced
+// stores), 16 values of the small one sit in registers (its operand row is a 32-byte broadcast), the four
+// waves of a block deal the tokens among them and meet in LDS.  LARGE_IS_M: out[m = large][n = small].
+template <bool LARGE_IS_M>
+__global__ __launch_bounds__(256) void tn_accum_wide_kernel(const bf16_t* __restrict__ a, int lda, const bf16_t* __restrict__ b,
+                                                            int ldb, float* __restrict__ out, int ldo, int T, int M, int N,
+                                                            float scale, int accumulate) {
+    __shared__ float red[4][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bf16_t* big = LARGE_IS_M ? a : b;
+    const bf16_t* small = LARGE_IS_M ? b : a;
+    const int ldbig = LARGE_IS_M ? lda : ldb, ldsm = LARGE_IS_M ? ldb : lda;
+    const int L = LARGE_IS_M ? M : N;
+    const int l = blockIdx.x * 64 + lane, s0 = blockIdx.y * 16;
+    const int lc = l < L ? l : L - 1;
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    for (int t = wave; t < T; t += 4) {
+        const float x = bf2f(big[(size_t)t * ldbig + lc]);
+        const uint4 s_lo = *reinterpret_cast<const uint4*>(small + (size_t)t * ldsm + s0);
+        const uint4 s_hi = *reinterpret_cast<const uint4*>(small + (size_t)t * ldsm + s0 + 8);
+        const bf16_t* pl = reinterpret_cast<const bf16_t*>(&s_lo);
+        const bf16_t* ph = reinterpret_cast<const bf16_t*>(&s_hi);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc[j] = fmaf(x, bf2f(pl[j]), acc[j]);
+            acc[8 + j] = fmaf(x, bf2f(ph[j]), acc[8 + j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) red[wave][j][lane] = acc[j];
+    __syncthreads();
+    for (int o = threadIdx.x; o < 16 * 64; o += 256) {
+        const int j = LARGE_IS_M ? (o & 15) : (o >> 6), ll = LARGE_IS_M ? (o >> 4) : (o & 63);
+        const int lg = blockIdx.x * 64 + ll;
+        if (lg >= L) continue;
+        const float v = scale * (red[0][j][ll] + red[1][j][ll] + red[2][j][ll] + red[3][j][ll]);
+        float* p = LARGE_IS_M ? out + (size_t)lg * ldo + s0 + j : out + (size_t)(s0 + j) * ldo + lg;
+        *p = (accumulate ? *p : 0.f) + v;
+    }
+}
+
 // D[t][h] = sum_d dO[t][h][d] * O[t][h][d]   (softmax backward row term)
 __global__ __launch_bounds__(256) void rowdot_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
                                                      float* __restrict__ out, size_t rows, int hs) {
@@ -218,6 +262,22 @@ extern "C" int dh_qkv_rope_bwd_bf16(const dh_bf16* dq, const dh_bf16* dk, const 
 extern "C" int dh_tn_accum_f32(const dh_bf16* a, int lda, const dh_bf16* b, int ldb, float* out, int ldo, int T, int M,
                                int N, float scale, int accumulate, void* stream) {
     DH_CHECK(a && b && out && T >= 0 && M > 0 && N > 0, "dh_tn_accum_f32: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    // the small operand is read as aligned 16-byte runs
+    const bool n_small = N % 16 == 0 && N <= 64 && M >= 64 && ldb % 8 == 0 && ((uintptr_t)b & 15) == 0;
+    const bool m_small = M % 16 == 0 && M <= 64 && N >= 64 && lda % 8 == 0 && ((uintptr_t)a & 15) == 0;
+    if (n_small) {
+        hipLaunchKernelGGL(tn_accum_wide_kernel<true>, dim3(cdiv(M, 64), N / 16), dim3(256), 0, st, a, lda, b, ldb, out, ldo, T, M,
+                           N, scale, accumulate);
+        DH_LAUNCH_CHECK();
+        return 0;
+    }
+    if (m_small) {
+        hipLaunchKernelGGL(tn_accum_wide_kernel<false>, dim3(cdiv(N, 64), M / 16), dim3(256), 0, st, a, lda, b, ldb, out, ldo, T, M,
+                           N, scale, accumulate);
+        DH_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(tn_accum_kernel, dim3(cdiv(M, 16), cdiv(N, 16)), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, out,
                        ldo, T, M, N, scale, accumulate);
     DH_LAUNCH_CHECK();

@@ -6,7 +6,7 @@ tensor or a missing library raises.
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+from typing import Sequence, Optional, Tuple
 
 import torch
 
@@ -289,17 +289,19 @@ def tn_accum(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, scale: float =
                                       T, M, N, float(scale), int(accumulate), _stream()))
 
 
-def attn_bwd(q, k, v, out, dout, lse, q_start, q_len, max_q_len: int):
-    """-> (dq, dk, dv) of the causal GQA attention of a packed batch (sequences attend to themselves)."""
+def attn_bwd(q, k, v, out, dout, lse, q_start, q_len, max_q_len: int, lens: Optional[Sequence[int]] = None):
+    """-> (dq, dk, dv) of the causal GQA attention of a packed batch (sequences attend to themselves).
+    `lens` = q_len on the host; when given nothing here touches the host (hipGraph capture of a training step)."""
     n_tok, H, hs = q.shape
     G = k.size(1)
     lib = _lib.load()
     dev = q.device
-    lens = q_len.tolist()
-    pads = [-(-n // 32) * 32 for n in lens]
-    pad_start = torch.tensor([sum(pads[:i]) for i in range(len(pads))], dtype=torch.int32, device=dev)
-    n_pad = sum(pads)
-    tok_seq = torch.repeat_interleave(torch.arange(len(lens), dtype=torch.int32, device=dev), q_len.to(torch.int64))
+    if lens is None:
+        lens = q_len.tolist()
+    n_pad = sum(-(-n // 32) * 32 for n in lens)
+    pads_dev = (q_len + 31) // 32 * 32
+    pad_start = (torch.cumsum(pads_dev, 0) - pads_dev).to(torch.int32)
+    tok_seq = torch.repeat_interleave(torch.arange(len(lens), dtype=torch.int32, device=dev), q_len.to(torch.int64), output_size=n_tok)
     dout = _dev(dout.reshape(n_tok, H, hs))
     dsum = torch.empty((n_tok, H), dtype=torch.float32, device=dev)
     check(lib.dh_rowdot_f32(_p(dout), _p(_dev(out.reshape(n_tok, H, hs))), _p(dsum), n_tok * H, hs, _stream()))

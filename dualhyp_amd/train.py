@@ -32,6 +32,7 @@ class _Frozen:
     def __init__(self, model: GPT) -> None:
         self.sig = tuple(p.data_ptr() for n, p in model.named_parameters() if "lora_" not in n)
         self.lm_T = model.lm_head.linear.weight.data.t().contiguous()                      # [d, V]
+        self.scale_is_one = bool((model.lm_head.adapter_scale.data == 1).all())
         self.layers = []
         for blk in model.transformer.h:
             w1, w2 = blk.mlp.fc_1.linear.weight.data, blk.mlp.fc_2.linear.weight.data
@@ -98,9 +99,9 @@ class _DecoderFn(torch.autograd.Function):
         if model.rope_cache is None or model.rope_cache[0].device != dev:
             model.rope_cache = model.build_rope_cache(idx)
         cos, sin = model.rope_cache
-        tail = None
+        tail = getattr(model, "_row_tail_override", None)      # GraphedTrainStep: flags of the UNPADDED call
         V = model.cpu_rsqrt_vec_width
-        if V:
+        if tail is None and V:
             tail = (torch.arange(n_tok, device=dev) >= n_tok // V * V).to(torch.uint8)
         tok_slot = torch.arange(B, dtype=i32, device=dev).repeat_interleave(T)
         tok_pos = torch.arange(T, dtype=i32, device=dev).repeat(B)
@@ -166,7 +167,7 @@ class _DecoderFn(torch.autograd.Function):
         dev = dlogits.device
         dz = dlogits.reshape(B * T, -1).to(BF)
         scale_vec = model.lm_head.adapter_scale.data
-        if not bool((scale_vec == 1).all()):
+        if not fz.scale_is_one:                                        # (frozen: checked once, no host sync here)
             dz = dz * scale_vec                                        # d(scale*(z+bias))/dz
         dz = dz.contiguous()
         dxf = ops.linear(dz, fz.lm_T)
@@ -199,7 +200,7 @@ class _DecoderFn(torch.autograd.Function):
             else:
                 dy = ops.linear(dx1, W["proj_T"])
             # ---- attention + rope
-            dq, dk, dv = ops.attn_bwd(L.q, L.k, L.v, L.y, dy, L.lse, q_start, q_len, T)
+            dq, dk, dv = ops.attn_bwd(L.q, L.k, L.v, L.y, dy, L.lse, q_start, q_len, T, lens=[T] * B)
             dqkv = ops.qkv_rope_bwd(dq, dk, dv, cos, sin, tok_pos)
             # ---- fused qkv projection (+LoRA, contiguous [Q|K|V] delta placement, quirk Q2)
             gA1 = gB1 = None
@@ -251,6 +252,92 @@ def _pad64(t: torch.Tensor) -> torch.Tensor:
     out = t.new_zeros((*t.shape[:-1], -(-k // 64) * 64))
     out[..., :k] = t
     return out
+
+
+class _Ctx:
+    """Stands in for autograd's ctx when the node is driven by hand (GraphedTrainStep)."""
+
+
+class GraphedTrainStep:
+    """One LoRA micro-step (micro-batch 1, as finetune/ger.py runs it) — forward, the reference's chunked
+    cross entropy (mean over ALL T-1 positions, Q5), backward, accumulation into the flat gradient bucket —
+    captured ONCE per padded length as a hipGraph and replayed.  The eager autograd path issues ~1500 launches
+    from Python per micro-step and is host-bound (48 ms at T = 560); the replay is one launch.
+    The sequence is right-padded to a multiple of `pad_to` with ignored positions: causal attention and the
+    row-wise kernels make real positions independent of the padding, ignored rows get zero gradient, and the
+    loss keeps the reference's denominator (T-1)."""
+
+    def __init__(self, model: GPT, bucket, pad_to: int = 64) -> None:
+        self.model, self.bucket, self.pad_to = model, bucket, pad_to
+        self.params = lora_parameters(model)
+        assert [id(p) for p in self.params] == [id(p) for p in bucket.params], "bucket must hold lora_parameters(model) in order"
+        self._graphs = {}
+
+    def _body(self, st) -> None:
+        model, V = self.model, self.model.config.padded_vocab_size
+        ctx = _Ctx()
+        model._row_tail_override = st["tail"] if model.cpu_rsqrt_vec_width else None
+        try:
+            logits = _DecoderFn.forward(ctx, model, st["ids"], *self.params)
+        finally:
+            model._row_tail_override = None
+        lg = logits.view(-1, V)
+        per, lse = ops.cross_entropy_fwd(lg, st["targets"])
+        st["loss"].copy_((per.sum() * st["inv_count"]).reshape(1))
+        dlogits = ops.cross_entropy_bwd(lg, st["targets"], lse, st["grow"])
+        grads = _DecoderFn.backward(ctx, dlogits.view(logits.shape))[2:]
+        off = 0
+        for p, g in zip(self.params, grads):
+            self.bucket.flat[off:off + p.numel()].add_(g.reshape(-1).to(torch.float32))
+            off += p.numel()
+
+    def _state(self, T_pad: int, dev):
+        st = dict(ids=torch.zeros((1, T_pad), dtype=torch.int64, device=dev),
+                  targets=torch.full((T_pad,), -1, dtype=torch.int64, device=dev),
+                  grow=torch.zeros(T_pad, dtype=torch.float32, device=dev),
+                  tail=torch.zeros(T_pad, dtype=torch.uint8, device=dev),
+                  inv_count=torch.zeros(1, dtype=torch.float32, device=dev),
+                  loss=torch.zeros(1, dtype=torch.float32, device=dev))
+        return st
+
+    @torch.no_grad()
+    def __call__(self, input_ids: torch.Tensor, labels: torch.Tensor, loss_scale: float = 1.0) -> torch.Tensor:
+        """-> the micro-step's loss (device tensor [1], finetune/ger.py:278-281); d(loss_scale * loss) is ADDED to the bucket."""
+        assert input_ids.dim() == 2 and input_ids.size(0) == 1, "GraphedTrainStep: micro-batch 1 (the reference's setting)"
+        T = input_ids.size(1)
+        T_pad = -(-T // self.pad_to) * self.pad_to
+        dev = input_ids.device
+        ent = self._graphs.get(T_pad)
+        if ent is None:
+            st = self._state(T_pad, dev)
+            ent = self._graphs[T_pad] = [st, None]
+        st = ent[0]
+        Vw = self.model.cpu_rsqrt_vec_width
+        st["ids"].zero_()
+        st["ids"][0, :T].copy_(input_ids[0])
+        st["targets"].fill_(-1)
+        st["targets"][: T - 1].copy_(labels[0, 1:])
+        st["grow"].fill_(loss_scale / max(T - 1, 1))
+        st["inv_count"].fill_(1.0 / max(T - 1, 1))
+        if Vw:
+            st["tail"].zero_()
+            st["tail"][T // Vw * Vw:T].fill_(1)
+        if ent[1] is None:
+            # warm-up outside capture (allocations, lazy initialisation), with its gradient contribution undone
+            keep = self.bucket.flat.clone()
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                self._body(st)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            self.bucket.flat.copy_(keep)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._body(st)
+            self.bucket.flat.copy_(keep)          # capture does not execute, but keep the invariant explicit
+            ent[1] = g
+        ent[1].replay()
+        return st["loss"].clone()
 
 
 def forward_train(model: GPT, idx: torch.Tensor, lm_head_chunk_size: int = 0) -> Union[torch.Tensor, List[torch.Tensor]]:

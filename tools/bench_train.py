@@ -31,3 +31,21 @@ dt = (time.perf_counter() - t0) / n
 flops = 2.43e12
 print(f"micro-step (T={T}, B=1): {dt*1e3:.1f} ms  ~{flops/dt/1e12:.0f} TFLOP/s algorithmic  loss {l.item():.3f}  grad-bucket {bucket.flat.numel()} fp32")
 print(f"peak memory {torch.cuda.max_memory_allocated()/2**30:.2f} GiB")
+
+# ---- the same micro-step captured once in a hipGraph and replayed (dualhyp_amd.train.GraphedTrainStep)
+from dualhyp_amd.train import GraphedTrainStep
+bucket.zero()
+for _ in range(2): step()
+ref = bucket.flat.clone(); ref_loss = l.item()
+bucket.zero()
+gs = GraphedTrainStep(m, bucket)
+m.eval_dropout = None
+lg = None
+for _ in range(2): lg = gs(ids, labels, 1.0 / 32)
+torch.cuda.synchronize()
+print(f"graph vs eager: loss {lg.item():.4f} vs {ref_loss:.4f}; grad relerr {((bucket.flat - ref).norm() / ref.norm()).item():.3e} (dropout masks differ between the runs)")
+t0 = time.perf_counter()
+for _ in range(n): lg = gs(ids, labels, 1.0 / 32)
+torch.cuda.synchronize()
+dtg = (time.perf_counter() - t0) / n
+print(f"graphed micro-step: {dtg*1e3:.1f} ms  ~{flops/dtg/1e12:.0f} TFLOP/s algorithmic")
