@@ -19,6 +19,8 @@
 #include "common.h"
 #include "gemm.h"
 
+int g_gemm128_stages = 0;   // 0: by grid size, else 2 or 4 (dh_set_tuning key 9)
+
 namespace {
 
 constexpr int BT = 128;   // block tile edge (both n and m)
@@ -27,9 +29,13 @@ constexpr int TILE_BYTES = BT * BK * 2;  // 16 KiB
 
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
-template <int EPI, bool RESID>
+// NST: LDS stages.  2: double buffer, two blocks per CU (large grids: a block's waits are covered by its
+// neighbour).  4: three K-tiles in flight with counted s_waitcnt, one block per CU — for grids smaller than
+// the chip (a training micro-batch: ~100 blocks each walking K alone, where the double buffer spends about
+// one memory latency per K-tile).
+template <int EPI, bool RESID, int NST>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // NST x (W tile 16 KiB + x tile 16 KiB)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wm = wave & 1;
 
@@ -102,12 +108,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
     const int sw = swz(lr);
 
     const int nk = a.K / BK;
-    stage(0, 0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-        const char* sA = smem + cur * 2 * TILE_BYTES;
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const char* sA = smem + buf * 2 * TILE_BYTES;
         const char* sB = sA + TILE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -124,7 +126,34 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();  // drains the stage's vmcnt and fences the buffer swap
+    };
+    if constexpr (NST == 2) {
+        stage(0, 0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+            compute(cur);
+            __syncthreads();  // drains the stage's vmcnt and fences the buffer swap
+        }
+    } else {
+        // 8 DMA requests per wave and stage; K-tile kt+1 must have landed at the end of iteration kt
+#pragma unroll
+        for (int p = 0; p < NST - 1; ++p)
+            if (p < nk) stage(p, p);
+        if (2 < nk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int kt = 0; kt < nk; ++kt) {
+            // slot (kt+3) % 4 was last read in iteration kt-1, which ended with a barrier
+            if (kt + 3 < nk) stage((kt + 3) % NST, kt + 3);
+            compute(kt % NST);
+            if (kt + 3 < nk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
     }
 
     // ---------------------------------------------------------------- epilogue
@@ -200,15 +229,25 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
     }
 }
 
-template <int EPI>
-int launch(const GemmArgs& a, hipStream_t s) {
-    dim3 grid(a.nb_n * a.nb_m), block(256);
-    if (a.resid)
-        hipLaunchKernelGGL((gemm_nt_kernel<EPI, true>), grid, block, 0, s, a);
-    else
-        hipLaunchKernelGGL((gemm_nt_kernel<EPI, false>), grid, block, 0, s, a);
+template <int EPI, bool RESID, int NST>
+int launch_n(const GemmArgs& a, hipStream_t s) {
+    constexpr int lds = NST * 2 * TILE_BYTES;
+    static bool attr = false;
+    if (!attr) {
+        DH_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, RESID, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm_nt_kernel<EPI, RESID, NST>), dim3(a.nb_n * a.nb_m), dim3(256), lds, s, a);
     DH_LAUNCH_CHECK();
     return 0;
+}
+
+template <int EPI>
+int launch(const GemmArgs& a, hipStream_t s) {
+    const int blocks = a.nb_n * a.nb_m;
+    const int nst = g_gemm128_stages ? g_gemm128_stages : (blocks < 384 ? 4 : 2);
+    if (nst == 4) return a.resid ? launch_n<EPI, true, 4>(a, s) : launch_n<EPI, false, 4>(a, s);
+    return a.resid ? launch_n<EPI, true, 2>(a, s) : launch_n<EPI, false, 2>(a, s);
 }
 
 }  // namespace

@@ -160,10 +160,11 @@ __global__ __launch_bounds__(256) void tn_accum_kernel(const bf16_t* __restrict_
 // stores), 16 values of the small one sit in registers (its operand row is a 32-byte broadcast), the four
 // waves of a block deal the tokens among them and meet in LDS.  LARGE_IS_M: out[m = large][n = small].
 template <bool LARGE_IS_M>
-__global__ __launch_bounds__(256) void tn_accum_wide_kernel(const bf16_t* __restrict__ a, int lda, const bf16_t* __restrict__ b,
-                                                            int ldb, float* __restrict__ out, int ldo, int T, int M, int N,
-                                                            float scale, int accumulate) {
-    __shared__ float red[4][16][64];
+__global__ __launch_bounds__(1024) void tn_accum_wide_kernel(const bf16_t* __restrict__ a, int lda, const bf16_t* __restrict__ b,
+                                                             int ldb, float* __restrict__ out, int ldo, int T, int M, int N,
+                                                             float scale, int accumulate) {
+    constexpr int NWV = 16, UN = 4;      // waves per block (tokens dealt over them), tokens in flight per wave
+    __shared__ float red[NWV][16][64];   // 64 KiB
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bf16_t* big = LARGE_IS_M ? a : b;
     const bf16_t* small = LARGE_IS_M ? b : a;
@@ -174,28 +175,42 @@ __global__ __launch_bounds__(256) void tn_accum_wide_kernel(const bf16_t* __rest
     float acc[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-    for (int t = wave; t < T; t += 4) {
-        const float x = bf2f(big[(size_t)t * ldbig + lc]);
-        const uint4 s_lo = *reinterpret_cast<const uint4*>(small + (size_t)t * ldsm + s0);
-        const uint4 s_hi = *reinterpret_cast<const uint4*>(small + (size_t)t * ldsm + s0 + 8);
-        const bf16_t* pl = reinterpret_cast<const bf16_t*>(&s_lo);
-        const bf16_t* ph = reinterpret_cast<const bf16_t*>(&s_hi);
+    for (int t0 = wave; t0 < T; t0 += NWV * UN) {
+        bf16_t xv[UN];
+        uint4 lo[UN], hi[UN];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            acc[j] = fmaf(x, bf2f(pl[j]), acc[j]);
-            acc[8 + j] = fmaf(x, bf2f(ph[j]), acc[8 + j]);
+        for (int u = 0; u < UN; ++u) {           // all loads of the round first: the loop is latency-bound otherwise
+            const int t = min(t0 + u * NWV, T - 1);
+            xv[u] = big[(size_t)t * ldbig + lc];
+            lo[u] = *reinterpret_cast<const uint4*>(small + (size_t)t * ldsm + s0);
+            hi[u] = *reinterpret_cast<const uint4*>(small + (size_t)t * ldsm + s0 + 8);
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const float x = t0 + u * NWV < T ? bf2f(xv[u]) : 0.f;
+            const bf16_t* pl = reinterpret_cast<const bf16_t*>(&lo[u]);
+            const bf16_t* ph = reinterpret_cast<const bf16_t*>(&hi[u]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                acc[j] = fmaf(x, bf2f(pl[j]), acc[j]);
+                acc[8 + j] = fmaf(x, bf2f(ph[j]), acc[8 + j]);
+            }
         }
     }
 #pragma unroll
     for (int j = 0; j < 16; ++j) red[wave][j][lane] = acc[j];
     __syncthreads();
-    for (int o = threadIdx.x; o < 16 * 64; o += 256) {
+    {
+        const int o = threadIdx.x;               // 1024 outputs, one per thread
         const int j = LARGE_IS_M ? (o & 15) : (o >> 6), ll = LARGE_IS_M ? (o >> 4) : (o & 63);
         const int lg = blockIdx.x * 64 + ll;
-        if (lg >= L) continue;
-        const float v = scale * (red[0][j][ll] + red[1][j][ll] + red[2][j][ll] + red[3][j][ll]);
-        float* p = LARGE_IS_M ? out + (size_t)lg * ldo + s0 + j : out + (size_t)(s0 + j) * ldo + lg;
-        *p = (accumulate ? *p : 0.f) + v;
+        if (lg < L) {
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) v += red[w][j][ll];
+            float* p = LARGE_IS_M ? out + (size_t)lg * ldo + s0 + j : out + (size_t)(s0 + j) * ldo + lg;
+            *p = (accumulate ? *p : 0.f) + scale * v;
+        }
     }
 }
 
@@ -267,13 +282,13 @@ extern "C" int dh_tn_accum_f32(const dh_bf16* a, int lda, const dh_bf16* b, int 
     const bool n_small = N % 16 == 0 && N <= 64 && M >= 64 && ldb % 8 == 0 && ((uintptr_t)b & 15) == 0;
     const bool m_small = M % 16 == 0 && M <= 64 && N >= 64 && lda % 8 == 0 && ((uintptr_t)a & 15) == 0;
     if (n_small) {
-        hipLaunchKernelGGL(tn_accum_wide_kernel<true>, dim3(cdiv(M, 64), N / 16), dim3(256), 0, st, a, lda, b, ldb, out, ldo, T, M,
+        hipLaunchKernelGGL(tn_accum_wide_kernel<true>, dim3(cdiv(M, 64), N / 16), dim3(1024), 0, st, a, lda, b, ldb, out, ldo, T, M,
                            N, scale, accumulate);
         DH_LAUNCH_CHECK();
         return 0;
     }
     if (m_small) {
-        hipLaunchKernelGGL(tn_accum_wide_kernel<false>, dim3(cdiv(N, 64), M / 16), dim3(256), 0, st, a, lda, b, ldb, out, ldo, T, M,
+        hipLaunchKernelGGL(tn_accum_wide_kernel<false>, dim3(cdiv(N, 64), M / 16), dim3(1024), 0, st, a, lda, b, ldb, out, ldo, T, M,
                            N, scale, accumulate);
         DH_LAUNCH_CHECK();
         return 0;
