@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Race screen for the kernels whose LDS hand-over rests on counted s_waitcnt + raw s_barrier (cdna_hip_programming.md
+§5 'place reads by the vmcnt/barrier count, never by clean runs'): many launches on fresh random data, several
+shapes, compared bit for bit with a structurally different kernel that computes the same chains.
+  * 256-tile GEMM: ping-pong loop (variant 1) and 4-stage loop (2) vs the __syncthreads double buffer (3)
+  * 128-tile GEMM: 4-stage counted-wait loop vs the 2-stage __syncthreads loop
+  * decode GEMMs: gemm_mid (loader waves) vs gemm_dt (tiled) rows; tiled chain vs ordered sum of K-sliced partials"""
+import sys, torch
+sys.path.insert(0, '.')
+from dualhyp_amd import ops, _lib
+lib = _lib.load()
+D = "cuda:0"
+g = torch.Generator(device=D).manual_seed(123)
+rn = lambda *s: (torch.randn(*s, device=D, generator=g) * 0.5).bfloat16()
+bad = 0
+def check(name, a, b):
+    global bad
+    if not torch.equal(a, b):
+        bad += 1
+        print(f"MISMATCH {name}: {(a != b).sum().item()} elements differ")
+REPS = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+for (M, N, K) in [(16384, 2560, 2048), (4096, 2048, 5632), (1024, 768, 512), (777, 1024, 2048), (256, 256, 64), (2304, 5632, 2048)]:
+    for it in range(REPS):
+        x, w, r = rn(M, K), rn(N, K) * 0.1, rn(M, N)
+        outs = []
+        for v in (3, 1, 2):
+            lib.dh_set_tuning(1, v)
+            outs.append(ops.linear(x, w, resid=r))
+        check(f"gemm256 pingpong M={M} N={N} K={K} it={it}", outs[1], outs[0])
+        check(f"gemm256 pipe M={M} N={N} K={K} it={it}", outs[2], outs[0])
+        if N % 64 == 0 and it % 4 == 0:
+            w2 = rn(N, K) * 0.1
+            so = []
+            for v in (3, 1):
+                lib.dh_set_tuning(1, v)
+                so.append(ops.linear(x, w, epilogue=ops.EPI_SWIGLU, w2=w2))
+            check(f"gemm256 swiglu M={M} N={N} K={K} it={it}", so[1], so[0])
+    print(f"gemm256 {M}x{N}x{K}: {REPS} runs done", flush=True)
+lib.dh_set_tuning(1, 1)
+for (M, N, K) in [(560, 2048, 2048), (560, 2560, 2048), (200, 512, 5632), (100, 128, 64)]:
+    for it in range(REPS):
+        x, w = rn(M, K), rn(N, K) * 0.1
+        lib.dh_set_tuning(1, 0)      # always the 128-tile kernel
+        lib.dh_set_tuning(9, 2); a = ops.linear(x, w)
+        lib.dh_set_tuning(9, 4); b = ops.linear(x, w)
+        check(f"gemm128 4-stage M={M} N={N} K={K} it={it}", b, a)
+    print(f"gemm128 {M}x{N}x{K}: {REPS} runs done", flush=True)
+lib.dh_set_tuning(1, 1); lib.dh_set_tuning(9, 0)
+lib.dh_set_tuning(4, 2)
+for (M, d, I) in [(256, 2048, 5632), (1024, 2048, 5632), (100, 512, 768)]:
+    for it in range(REPS):
+        x, w1, w2 = rn(M, d), rn(I, d) * 0.1, rn(I, d) * 0.1
+        lib.dh_set_tuning(6, 1 << 20); a = ops.linear(x, w1, epilogue=ops.EPI_SWIGLU, w2=w2)     # gemm_mid
+        for st in (2, 4):
+            lib.dh_set_tuning(6, 65); lib.dh_set_tuning(8, st); b = ops.linear(x, w1, epilogue=ops.EPI_SWIGLU, w2=w2)   # gemm_dt
+            check(f"mid vs dt({st}) swiglu M={M} d={d} it={it}", b, a)
+        A = rn(48, d) * 0.1
+        wq = rn(d + 512, d) * 0.1
+        ks = (d // 32 + 7) // 8
+        parts = ops.linear_partial(x, wq, A, ksplit=ks)
+        seq = parts[0].clone()
+        for p in range(1, ks):
+            seq = seq + parts[p]
+        lib.dh_set_tuning(7, 65)
+        for st in (2, 4):
+            lib.dh_set_tuning(8, st)
+            check(f"chain({st}) vs partials M={M} d={d} it={it}", ops.linear_chain(x, wq, A, ksplit=ks), seq)
+    print(f"decode GEMMs M={M} d={d}: {REPS} runs done", flush=True)
+lib.dh_set_tuning(6, 193); lib.dh_set_tuning(7, 768); lib.dh_set_tuning(8, 0); lib.dh_set_tuning(4, 0)
+print("race screen:", "CLEAN" if bad == 0 else f"{bad} MISMATCHES")
+sys.exit(1 if bad else 0)
