@@ -1,4 +1,4 @@
-// y[M, N] = epilogue(x · W^T) for the decode step, M <= 256 rows (one 32-sequence batch, or several
+// y[M, N] = epilogue(x · W^T) for the decode step, M <= 192 rows in practice (one 32-sequence batch, or several
 // batches decoded jointly: generate.py generate_batch).  HBM-bound weight streaming; x is staged
 // ONCE per block in LDS and shared by the 8 waves instead of being fetched per wave from L2 as
 // gemm_skinny.hip does.

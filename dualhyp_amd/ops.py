@@ -184,7 +184,7 @@ def cross_entropy_bwd(logits: torch.Tensor, targets: torch.Tensor, lse: torch.Te
 
 
 def linear_partial(x: torch.Tensor, w: torch.Tensor, w_ext: Optional[torch.Tensor] = None, ksplit: int = 1) -> torch.Tensor:
-    """fp32 partial sums [ksplit, M, n_main+n_ext] of x @ [w; w_ext].T (M <= 32); dh_linear_partial_bf16."""
+    """fp32 partial sums [ksplit, M, n_main+n_ext] of x @ [w; w_ext].T (decode rows, M <= 4096); dh_linear_partial_bf16."""
     x, w = _dev(x, name="x"), _dev(w, name="w")
     K = x.size(-1)
     M = x.numel() // K

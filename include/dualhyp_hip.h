@@ -86,14 +86,15 @@ int dh_qkv_rope_cache_bf16(const dh_bf16* qkv, const dh_bf16* cos, const dh_bf16
  *  SWIGLU : w2 [N,K] second weight (fc_2); W is fc_1.
  *  ADAPTER: vec_a = adapter_scale[N], vec_b = adapter_bias[N].
  *  resid  : if non-NULL, y = bf16(resid + y_epilogue)  (residual add of ger/model.py:185-186)
- *  M may be any value >= 1; for M <= 32 a weight-streaming kernel is used. */
+ *  M may be any value >= 1; for M <= 32 a weight-streaming kernel is used, otherwise the tiled MFMA kernels
+ *  (the engine additionally pins the kernel family per phase: see DESIGN.md, batch invariance). */
 int dh_linear_bf16(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N, int K,
                    int epilogue, const dh_bf16* w2, const dh_bf16* xa, int xa_ld,
                    const dh_bf16* lora_b, float lora_scale, int split0, int split1,
                    const dh_bf16* vec_a, const dh_bf16* vec_b, const dh_bf16* resid,
                    void* stream);
 
-/* fp32 partial sums for the fused decode consumers below (M <= 256, weight streaming):
+/* fp32 partial sums for the fused decode consumers below (M <= 4096 rows, weight streaming):
  *   y32[p][m][n] = sum over K-slice p of x[m,:] . W'[n,:],  W' = [w (n_main rows) ; w_ext (n_ext rows)]
  * y32: [ksplit][M][n_main+n_ext] fp32.  w_ext is the rank-padded LoRA A (so x·A^T comes out of the
  * same pass over x as x·W^T and never needs its own launch).  K %% 32 == 0, rows %% 16 == 0. */
