@@ -38,7 +38,7 @@ def generate_batch(model: GPT, prompts: Sequence[torch.Tensor], max_new_tokens: 
         raise NotImplementedError(f"max_seq_length {model.max_seq_length} needs to be >= {need_pos}")
     dev = model.transformer.wte.weight.device
     chunks = [(c, min(c + prefill_batch, B)) for c in range(0, B, prefill_batch)]
-    eng = model.engine(B, need_pos, max(sum(lens[a:b]) for a, b in chunks))
+    eng = model.engine(B, need_pos, max(sum(lens[a:b]) for a, b in chunks), exact=B > prefill_batch)
     tok_ld = T_max + max_new_tokens
     if min(lens) == T_max:             # equal lengths: one copy
         tokens = torch.nn.functional.pad(torch.stack([p.to(dev) for p in prompts]), (0, tok_ld - T_max))

@@ -471,12 +471,20 @@ class GPT(nn.Module):
             self._capacity = cap
             self._drop_engine()
 
-    def engine(self, need_batch: int = 1, need_pos: int = 1, need_tokens: int = 1) -> _Engine:
+    def engine(self, need_batch: int = 1, need_pos: int = 1, need_tokens: int = 1, exact: bool = False) -> _Engine:
+        """The engine, grown (cache contents dropped) when the request does not fit.  By default the cache is
+        sized like the reference's (max_seq_length positions, ger/lora.py:542: later calls at higher positions
+        must not re-allocate) with room for max_batch x 1024 packed tokens; `exact=True` (generate_batch, which
+        knows its whole need up front) allocates what was asked for — 2048 sequences x 640 positions is 30 GB,
+        at max_seq_length it would be 94 GB plus 77 GB of workspace."""
         cap = self._capacity
         if cap["s_max"] == 0 or need_batch > cap["max_batch"] or need_pos > cap["s_max"] or need_tokens > cap["max_tokens"]:
             mb = max(cap["max_batch"], need_batch)
-            s_need = max(cap["s_max"], need_pos, self.max_seq_length)
-            self.set_capacity(mb, s_need, max(cap["max_tokens"], need_tokens, mb * min(s_need, 1024)))
+            if exact:   # nothing inherited from an earlier, reference-sized allocation
+                self.set_capacity(need_batch, need_pos, max(need_tokens, need_batch))
+            else:
+                s_need = max(cap["s_max"], need_pos, self.max_seq_length)
+                self.set_capacity(mb, s_need, max(cap["max_tokens"], need_tokens, mb * min(s_need, 1024)))
         if self._engine is not None and self._engine.signature != self._param_signature():
             self._drop_engine()
         if self._engine is None:

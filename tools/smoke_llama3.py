@@ -30,3 +30,13 @@ o = generate_batch(m, corpus[B:], G, temperature=0.2, top_k=1)
 torch.cuda.synchronize(); dt = time.time() - t0
 assert all(x.numel() == T + G for x in o)
 print(f"Llama-3-8B bf16, batch {B}, {T}-token prompts -> {G} tokens: {dt*1e3:.0f} ms = {B/dt:.1f} utt/s (1 GPU, one batch in flight)")
+
+# several batches decoded jointly (chunked prefill of 32, one decode loop)
+for Gn in (4, 8):
+    corpus = [p.to(dev) for p in synth_prompts(B * Gn, T, V, seed=2)]
+    if Gn == 4:
+        generate_batch(m, corpus, G, temperature=0.2, top_k=1, prefill_batch=B)      # allocation + graph capture
+    torch.cuda.synchronize(); t0 = time.time()
+    o = generate_batch(m, corpus, G, temperature=0.2, top_k=1, prefill_batch=B)
+    torch.cuda.synchronize(); dt = time.time() - t0
+    print(f"Llama-3-8B bf16, {Gn} batches of {B} decoded jointly: {dt*1e3:.0f} ms = {B*Gn/dt:.1f} utt/s (1 GPU)", flush=True)
