@@ -35,8 +35,9 @@ __global__ __launch_bounds__(HS == 64 ? 1024 : 512) void attn_prefill_kernel(
     constexpr int KS = HS / 16;   // k-steps of the QK product
     constexpr int DT = HS / 32;   // 32-row tiles of O^T
     constexpr int TILE_B = HS * 32 * 2;   // bytes of one 32-key tile of K (and of V^T)
-    __shared__ __attribute__((aligned(16))) char sK[2 * TILE_B];
-    __shared__ __attribute__((aligned(16))) char sV[2 * TILE_B];
+    // two stages of (two 32-key tiles of K, two of V^T): the tiles of step kt+1 are DMA'd (global_load_lds; the
+    // cache is already in fragment order, so the copy is linear) while step kt is multiplied
+    __shared__ __attribute__((aligned(16))) char sKV[2][4 * TILE_B];
 
     const int seq = blockIdx.z, g = blockIdx.y;
     const int qt = gridDim.x - 1 - blockIdx.x;          // longest (latest) tiles first
@@ -73,20 +74,26 @@ __global__ __launch_bounds__(HS == 64 ? 1024 : 512) void attn_prefill_kernel(
     const int n_tiles = last_key / 64 + 1;
     const int q_abs = p0 + lr;
 
+    // one-KiB groups (64 lanes x 16 B) of a stage dealt over the waves: 2*TILE_B/1024 of K then as many of V^T
+    constexpr int GRP = 2 * TILE_B / 1024;
+    const int nwaves = nthr >> 6;
+    auto stage = [&](int buf, int kt) __attribute__((always_inline)) {
+        const char* gk = reinterpret_cast<const char*>(kbase + (size_t)(2 * kt) * HS * 32);
+        const char* gv = reinterpret_cast<const char*>(vbase + (size_t)(2 * kt) * HS * 32);
+        for (int gidx = wave; gidx < 2 * GRP; gidx += nwaves) {
+            const char* src = gidx < GRP ? gk + gidx * 1024 : gv + (gidx - GRP) * 1024;
+            glds16(src + lane * 16, sKV[buf] + gidx * 1024);
+        }
+    };
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     for (int kt = 0; kt < n_tiles; ++kt) {
         const int key0 = kt * 64;
-        __syncthreads();
-        // ---- stage the two 32-key tiles of K and of V^T: linear copies (the cache is already in
-        // fragment order).  Keys beyond last_key are masked below; the cache is finite everywhere.
-        {
-            const uint4* gk = reinterpret_cast<const uint4*>(kbase + (size_t)(2 * kt) * HS * 32);
-            const uint4* gv = reinterpret_cast<const uint4*>(vbase + (size_t)(2 * kt) * HS * 32);
-            for (int c = tid; c < 2 * TILE_B / 16; c += nthr) {
-                reinterpret_cast<uint4*>(sK)[c] = gk[c];
-                reinterpret_cast<uint4*>(sV)[c] = gv[c];
-            }
-        }
-        __syncthreads();
+        // buffer (kt+1)&1 was last read in iteration kt-1, which ended with a barrier
+        if (kt + 1 < n_tiles) stage((kt + 1) & 1, kt + 1);
+        const char* sK = sKV[kt & 1];
+        const char* sV = sK + 2 * TILE_B;
 
         // ---- S^T = K · Q^T for the two 32-key row tiles
         f32x16 st[2];
@@ -145,6 +152,8 @@ __global__ __launch_bounds__(HS == 64 ? 1024 : 512) void attn_prefill_kernel(
                     o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf.v, o[dt], 0, 0, 0);
                 }
             }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next stage has landed
+        __syncthreads();                                    // ... everybody's, and this stage's reads are done
     }
 
     // ---- normalise and store y[q][head*HS + d]
