@@ -197,6 +197,16 @@ def main() -> None:
         result["roofline_decode"] = {"bound": "hbm", "achieved": step_bytes / (step_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                      "frac": step_bytes / (step_ms * 1e-3) / 1e9 / 8000.0,
                                      "bytes_per_decode_step": step_bytes, "kernel": "decode step (157 launches: streaming GEMMs + fused attention)"}
+    if rank == 0 and world == 1 and a.schedule == "merged" and not a.no_overlap_probe and G > 1:
+        # informational: the same engine with ONE batch in flight (prefill, decode 32 rows, next batch)
+        reps = [batches[i % n_batches] for i in range(6)]
+        generate_batch(model, reps[0], NEW_TOKENS, prefill_batch=B, **gen_kw)      # decode graph for 32 rows
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for b in reps:
+            generate_batch(model, b, NEW_TOKENS, prefill_batch=B, **gen_kw)
+        torch.cuda.synchronize()
+        result["one_batch_in_flight"] = {"steps": len(reps), "value": B * len(reps) / (time.perf_counter() - t1), "unit": "utterances/s"}
     if rank == 0 and world == 1 and a.schedule == "merged" and not a.no_overlap_probe:
         # informational, outside the timed region of `value`: two engines on two HIP streams, each decoding G
         # batches jointly, so one engine's latency-bound decode loop runs under the other's prefills.  Higher
