@@ -198,6 +198,20 @@ def test_joint_decode_is_batch_invariant(golden, name):
             assert torch.equal(o, joint[a + i]), f"row {a + i} differs between the 70-row and the 16-row decode"
     alone = generate(m, prompts[37], prompts[37].numel() + G, temperature=0.2, top_k=1).cpu()
     assert torch.equal(alone, joint[37])
+    # EOS inside a joint decode: rows stop independently (device-side done flags), the EOS is excluded (Q7)
+    flat = torch.cat([o[p.numel():] for o, p in zip(joint, prompts)])
+    eos = int(torch.bincount(flat, minlength=V).argmax())          # a token the greedy decode produces often
+    je = [o.cpu() for o in generate_batch(m, prompts, G, temperature=0.2, top_k=1, eos_id=eos, prefill_batch=16)]
+    stopped = 0
+    for i, (o, full, p) in enumerate(zip(je, joint, prompts)):
+        gen = full[p.numel():]
+        hit = (gen == eos).nonzero()
+        want = full if hit.numel() == 0 else full[: p.numel() + int(hit[0])]
+        stopped += hit.numel() > 0
+        assert torch.equal(o, want), f"row {i}: EOS handling differs in the joint decode"
+    assert stopped >= 3
+    ae = generate(m, prompts[5], prompts[5].numel() + G, temperature=0.2, top_k=1, eos_id=eos).cpu()
+    assert torch.equal(ae, je[5])
 
 
 def test_full_tinyllama_vs_reference(golden):
