@@ -60,6 +60,9 @@ def main() -> None:
                     help="merged: one engine, chunked prefill + joint decode (generate_batch); threads: one engine, "
                          "HIP stream and host thread per in-flight batch (dualhyp_amd.pipeline)")
     ap.add_argument("--engines", type=int, default=2, help="--schedule threads: engines (each decodes --in-flight batches jointly)")
+    ap.add_argument("--prefill-batches", type=int, default=2,
+                    help="batches per prefill launch (merged schedule): at 2 x 32 x 512 tokens every GEMM of the layer is a whole "
+                         "number of 256-tile rounds on 256 CUs (the qkv GEMM is 2.5 rounds at one batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap-probe", action="store_true")
     a = ap.parse_args()
@@ -115,7 +118,7 @@ def main() -> None:
         outs = []
         for g in range(0, len(bs), G):
             flat = [p for b in bs[g:g + G] for p in b]
-            o = generate_batch(model, flat, NEW_TOKENS, prefill_batch=B, timing=phase, **gen_kw)
+            o = generate_batch(model, flat, NEW_TOKENS, prefill_batch=B * a.prefill_batches, timing=phase, **gen_kw)
             outs += [o[i:i + B] for i in range(0, len(o), B)]
         return outs
 
@@ -178,7 +181,8 @@ def main() -> None:
                                    "synthetic 5+5-hyp prompts, 512-token prompt -> 64 generated tokens, greedy",
                        "batch_per_gpu": B, "prompt_tokens": PROMPT_LEN, "new_tokens": NEW_TOKENS,
                        "parallelism": f"replicas x{world}", "batches_in_flight_per_gpu": G, "schedule": a.schedule,
-                       "decode_rows_per_launch": B * min(G, a.steps) if a.schedule == "merged" else B},
+                       "decode_rows_per_launch": B * min(G, a.steps) if a.schedule == "merged" else B,
+                       "prefill_tokens_per_launch": B * PROMPT_LEN * (a.prefill_batches if a.schedule == "merged" else 1)},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt256_kernel (prefill GEMMs: qkv+LoRA, proj+LoRA, fc_1/fc_2 SwiGLU, mlp proj)",
                          "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,

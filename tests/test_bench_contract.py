@@ -30,3 +30,4 @@ def test_bench_line_has_the_contract_fields():
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert 0.05 < r["frac"] < 1.0 and d["value"] > 50
     assert d["roofline_decode"]["bound"] == "hbm" and 32 <= d["phases"]["decode_rows_per_launch"] <= 64   # groups of 2 and 1 batches
+    assert d["config"]["prefill_tokens_per_launch"] == 2 * 32 * 512
