@@ -271,35 +271,34 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
     }
 
     // ---------------------------------------------------------------- epilogue
-    // acc[i][j][r]: n = nt + 4*kg + r , m = mt + frow
+    // acc[i][j][r]: n = nt + 4*kg + r , m = mt + frow: a lane holds 4 consecutive n (8 bytes of bf16) of one
+    // row; the four kg lanes of a row hold one 16-column tile.  Tiles are finished in PAIRS and one
+    // v_permlane16_swap per dword regroups them so that every lane owns 8 consecutive columns:
+    //   kg0: tile i   cols 0..7     kg2: tile i   cols 8..15     kg1: tile i+1 cols 0..7     kg3: tile i+1 cols 8..15
+    // -> one 16-byte store per lane and tile pair instead of two 8-byte ones (the tail of a tile is store-
+    // issue-bound, cdna_hip_programming.md T21), 64 contiguous bytes per row and instruction.
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    constexpr int NT = EPI == DH_EPI_SWIGLU ? 4 : 8;              // output tiles of 16 columns per wave
+    const int nw0 = n0 + wn * (NT * 16);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int m = m0 + wm * 64 + j * 16 + frow;
         const bool m_ok = m < a.M;
-        if (EPI == DH_EPI_SWIGLU) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int n = n0 + wn * 64 + i * 16 + kg * 4;
-                float o[4];
+        // packed bf16 x4 of output tile i for this lane (all lanes run it: the swap below is wave-wide)
+        auto tile_value = [&](int i) __attribute__((always_inline)) -> uint2 {
+            const int nt = nw0 + i * 16, n = nt + kg * 4;
+            const bool ok = m_ok && n < a.N;
+            float o[4];
+            if (EPI == DH_EPI_SWIGLU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float g = rbf(acc[i][j][e]);
                     const float u = rbf(acc[i + 4][j][e]);
-                    const float s = rbf(g / (1.0f + expf(-g)));
-                    o[e] = s * u;
+                    o[e] = rbf(g / (1.0f + expf(-g))) * u;
                 }
-                if (m_ok && n < a.N) {
-                    uint2 pk = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
-                    *reinterpret_cast<uint2*>(a.y + (size_t)m * a.N + n) = pk;
-                }
-            }
-        } else {
+            } else {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int nt = n0 + wn * 128 + i * 16;
-                const int n = nt + kg * 4;
-                f32x4 lacc = {0.f, 0.f, 0.f, 0.f};
+                for (int e = 0; e < 4; ++e) o[e] = rbf(acc[i][j][e]);
                 if (EPI == DH_EPI_LORA) {
                     const int seg = (nt >= a.split0) + (nt >= a.split1);
                     int nn = nt + frow;
@@ -310,17 +309,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
                         lb = *reinterpret_cast<const bf16x8*>(a.lora_b + (size_t)nn * 16 + kg * 8);
                         xf = *reinterpret_cast<const bf16x8*>(a.xa + (size_t)mm * a.xa_ld + seg * 16 + kg * 8);
                     }
+                    f32x4 lacc = {0.f, 0.f, 0.f, 0.f};
                     lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lb, xf, lacc, 0, 0, 0);
-                }
-                if (!(m_ok && n < a.N)) continue;
-                float o[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = rbf(acc[i][j][e]);
-                if (EPI == DH_EPI_LORA) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = rbf(o[e] + rbf(rbf(lacc[e]) * a.lora_scale));
                 }
-                if (EPI == DH_EPI_ADAPTER) {
+                if (EPI == DH_EPI_ADAPTER && ok) {
                     const uint2 sc = *reinterpret_cast<const uint2*>(a.vec_a + n);
                     const uint2 bi = *reinterpret_cast<const uint2*>(a.vec_b + n);
                     const bf16_t* sp = reinterpret_cast<const bf16_t*>(&sc);
@@ -328,14 +322,29 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = rbf(bf2f(sp[e]) * rbf(o[e] + bf2f(bp[e])));
                 }
-                if (RESID) {
+                if (RESID && ok) {
                     const uint2 rr = *reinterpret_cast<const uint2*>(a.resid + (size_t)m * a.N + n);
                     const bf16_t* rp = reinterpret_cast<const bf16_t*>(&rr);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = bf2f(rp[e]) + o[e];
                 }
-                uint2 pk = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
-                *reinterpret_cast<uint2*>(a.y + (size_t)m * a.N + n) = pk;
+            }
+            return make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+        };
+#pragma unroll
+        for (int ip = 0; ip < NT / 2; ++ip) {
+            uint2 ta = tile_value(2 * ip), tb = tile_value(2 * ip + 1);
+            const int nb = nw0 + ip * 32;                        // first column of the pair (wave-uniform)
+            if (nb + 32 <= a.N) {
+                const auto rx = __builtin_amdgcn_permlane16_swap(ta.x, tb.x, false, false);
+                const auto ry = __builtin_amdgcn_permlane16_swap(ta.y, tb.y, false, false);
+                if (m_ok)
+                    *reinterpret_cast<uint4*>(a.y + (size_t)m * a.N + nb + (kg & 1) * 16 + (kg >> 1) * 8) =
+                        make_uint4(rx[0], ry[0], rx[1], ry[1]);
+            } else {                                             // a pair straddling N: the narrow stores
+                const int na = nb + kg * 4;
+                if (m_ok && na < a.N) *reinterpret_cast<uint2*>(a.y + (size_t)m * a.N + na) = ta;
+                if (m_ok && na + 16 < a.N) *reinterpret_cast<uint2*>(a.y + (size_t)m * a.N + na + 16) = tb;
             }
         }
     }
