@@ -53,6 +53,33 @@ def _frozen(model: GPT) -> _Frozen:
     return fz
 
 
+def _lora_views(mod, qkv: bool):
+    """bf16, rank-padded operands of one LoRA module for the forward and backward kernels, rebuilt only when
+    the fp32 masters changed (an optimizer step), not at every micro-step: (A, B, A^T, B^T[, block B^T]).
+    Under hipGraph capture nothing is cached — the casts must be part of the captured step."""
+    key = (mod.lora_A.data_ptr(), mod.lora_A._version, mod.lora_B.data_ptr(), mod.lora_B._version)
+    capturing = torch.cuda.is_current_stream_capturing()
+    hit = getattr(mod, "_train_views", None)
+    if hit is not None and hit[0] == key and not capturing:
+        return hit[1]
+    A, B = mod.padded_lora()
+    At, Bt = A.t().contiguous(), B.t().contiguous()
+    views = [A, B, At, Bt]
+    if qkv:
+        qd = B.size(0)
+        s0, s1 = mod.splits
+        bounds = (0, s0, s1, qd)
+        Bblk = torch.zeros((64, qd), dtype=BF, device=B.device)      # block-structured B^T, rank slots 48..63 zero
+        for seg in range(3):
+            Bblk[16 * seg:16 * seg + 16, bounds[seg]:bounds[seg + 1]] = B[bounds[seg]:bounds[seg + 1]].t()
+        views += [Bblk, _pad64(At)]
+    else:
+        views += [_pad64(At)]
+    if not capturing:
+        mod._train_views = (key, views)
+    return views
+
+
 def lora_parameters(model: GPT) -> List[torch.nn.Parameter]:
     """The trainable tensors in the fixed order the autograd node uses."""
     out = []
@@ -121,7 +148,7 @@ class _DecoderFn(torch.autograd.Function):
             L.x = x
             L.n1 = ops.rmsnorm(x, blk.norm_1.weight.data, cfg.norm_eps, row_tail=tail)
             if qkv_m.lora_active:
-                A48, B16 = qkv_m.padded_lora()
+                A48, B16 = _lora_views(qkv_m, True)[:2]
                 L.n1d, L.mask1 = _drop(L.n1, p_drop, training)
                 L.xa = ops.linear(L.n1d, A48)
                 qkv = ops.linear(L.n1, qkv_m.linear.weight.data, epilogue=ops.EPI_LORA, xa=L.xa, lora_b=B16,
@@ -135,7 +162,7 @@ class _DecoderFn(torch.autograd.Function):
             L.lse = torch.empty((n_tok, H), dtype=torch.float32, device=dev)
             L.y = ops.attn_prefill(L.q, kc, vt, seq_slot, q_start, q_len, zeros, T, lse=L.lse)
             if proj_m.lora_active:
-                Ap, Bp = proj_m.padded_lora()
+                Ap, Bp = _lora_views(proj_m, False)[:2]
                 L.yd, L.mask2 = _drop(L.y, p_drop, training)
                 L.xa2 = ops.linear(L.yd, Ap)
                 L.x1 = ops.linear(L.y, proj_m.linear.weight.data, epilogue=ops.EPI_LORA, xa=L.xa2, lora_b=Bp,
@@ -186,15 +213,15 @@ class _DecoderFn(torch.autograd.Function):
             gA2 = gB2 = None
             if proj_m.lora_active:
                 s = proj_m.scaling
-                Ap, Bp = proj_m.padded_lora()                           # [16,d], [d,16]
-                t = ops.linear(dx1, Bp.t().contiguous())                # dx1 · Bp           [n,16]
+                Ap, Bp, ApT, BpT, ApT64 = _lora_views(proj_m, False)    # [16,d], [d,16] and transposes
+                t = ops.linear(dx1, BpT)                                # dx1 · Bp           [n,16]
                 if L.mask2 is None:
-                    dy = ops.linear(dx1, W["proj_T"], epilogue=ops.EPI_LORA, xa=t, lora_b=Ap.t().contiguous(), lora_scale=s)
+                    dy = ops.linear(dx1, W["proj_T"], epilogue=ops.EPI_LORA, xa=t, lora_b=ApT, lora_scale=s)
                 else:
-                    lo = ops.linear(_pad64(t), _pad64(Ap.t().contiguous()))
+                    lo = ops.linear(_pad64(t), ApT64)
                     dy = ops.linear(dx1, W["proj_T"], resid=(lo * L.mask2 * s).contiguous())
-                gB2 = torch.zeros((d, 16), dtype=torch.float32, device=dev)
-                gA2 = torch.zeros((16, d), dtype=torch.float32, device=dev)
+                gB2 = torch.empty((d, 16), dtype=torch.float32, device=dev)      # written whole (accumulate=False)
+                gA2 = torch.empty((16, d), dtype=torch.float32, device=dev)
                 ops.tn_accum(dx1, L.xa2, gB2, scale=s, accumulate=False)
                 ops.tn_accum(t, L.yd, gA2, scale=s, accumulate=False)
             else:
@@ -206,22 +233,19 @@ class _DecoderFn(torch.autograd.Function):
             gA1 = gB1 = None
             if qkv_m.lora_active:
                 s = qkv_m.scaling
-                A48, B16 = qkv_m.padded_lora()                          # [48,d], [qkv,16]
+                A48, B16, _, _, Bblk, A48T64 = _lora_views(qkv_m, True)  # [48,d], [qkv,16], block B^T [64,qkv], A^T [d,64]
                 qd = B16.size(0)
                 s0, s1 = qkv_m.splits
                 bounds = (0, s0, s1, qd)
-                Bblk = torch.zeros((64, qd), dtype=BF, device=dev)      # block-structured B^T, rank slots 48..63 zero
-                for seg in range(3):
-                    Bblk[16 * seg:16 * seg + 16, bounds[seg]:bounds[seg + 1]] = B16[bounds[seg]:bounds[seg + 1]].t()
                 t3 = ops.linear(dqkv, Bblk)                              # [n,64], cols 16seg.. = dqkv[:,seg] · B_seg
-                lo = ops.linear(t3, _pad64(A48.t().contiguous()))        # [n,d] = t3 · A48
+                lo = ops.linear(t3, A48T64)                              # [n,d] = t3 · A48
                 lo = lo * s if L.mask1 is None else lo * L.mask1 * s
                 dn1 = ops.linear(dqkv, W["qkv_T"], resid=lo.contiguous())
-                gB1 = torch.zeros((qd, 16), dtype=torch.float32, device=dev)
+                gB1 = torch.empty((qd, 16), dtype=torch.float32, device=dev)    # every segment written whole below
                 for seg in range(3):
                     ops.tn_accum(dqkv[:, bounds[seg]:bounds[seg + 1]], L.xa[:, 16 * seg:16 * seg + 16],
                                  gB1[bounds[seg]:bounds[seg + 1]], scale=s, accumulate=False)
-                gA1 = torch.zeros((48, d), dtype=torch.float32, device=dev)
+                gA1 = torch.empty((48, d), dtype=torch.float32, device=dev)
                 ops.tn_accum(t3[:, :48], L.n1d, gA1, scale=s, accumulate=False)
             else:
                 dn1 = ops.linear(dqkv, W["qkv_T"])
