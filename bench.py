@@ -63,6 +63,8 @@ def main() -> None:
     ap.add_argument("--prefill-batches", type=int, default=2,
                     help="batches per prefill launch (merged schedule): at 2 x 32 x 512 tokens every GEMM of the layer is a whole "
                          "number of 256-tile rounds on 256 CUs (the qkv GEMM is 2.5 rounds at one batch)")
+    ap.add_argument("--ragged", action="store_true",
+                    help="SURVEY §8d ragged variant: prompt lengths uniform in [384, 640] instead of 512 (not the headline config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap-probe", action="store_true")
     a = ap.parse_args()
@@ -102,8 +104,9 @@ def main() -> None:
     # every rank gets its own utterances (strided shard of one synthetic corpus)
     n_warm = max(a.warmup, 1)
     n_batches = a.steps + n_warm
-    corpus = synth_prompts(B * n_batches * world, PROMPT_LEN, cfg.padded_vocab_size, seed=1337)
+    corpus = synth_prompts(B * n_batches * world, PROMPT_LEN, cfg.padded_vocab_size, seed=1337, ragged=a.ragged, lo=384, hi=640)
     mine = [p.to(dev) for p in corpus[rank::world]]
+    max_len = max(p.numel() for p in mine)
     batches = [mine[i * B:(i + 1) * B] for i in range(n_batches)]
 
     def barrier():
@@ -123,7 +126,9 @@ def main() -> None:
         return outs
 
     if a.schedule == "merged":
-        # untimed: allocation + decode-graph capture at the in-flight size(s) the timed region uses
+        # one allocation for the whole run (ragged prompts would otherwise grow the engine inside the timed region)
+        model.set_capacity(B * min(G, a.steps), max_len + NEW_TOKENS, B * a.prefill_batches * max_len)
+        # untimed: decode-graph capture at the in-flight size(s) the timed region uses
         run_merged([batches[i % n_warm] for i in range(min(G, a.steps))])
         if a.steps % G and a.steps > G:
             run_merged([batches[0]] * (a.steps % G))
@@ -133,7 +138,7 @@ def main() -> None:
         # `engines` engines, each with its own KV cache, workspace, decode graph, HIP stream and host thread,
         # sharing one copy of the weights; each takes groups of G batches (chunked prefill + joint decode), so
         # one engine's latency-bound decode loop overlaps the other's prefills
-        pipe = BatchPipeline(model, a.engines, B * G, PROMPT_LEN + NEW_TOKENS, B * PROMPT_LEN)
+        pipe = BatchPipeline(model, a.engines, B * G, max_len + NEW_TOKENS, B * max_len)
         flat = lambda bs: [p for b in bs for p in b]
         pipe.warm(flat([batches[0]] * min(G, a.steps)), NEW_TOKENS, prefill_batch=B, **gen_kw)
         engs = [m.engine() for m in pipe.models]
@@ -156,7 +161,8 @@ def main() -> None:
         gemm_ms, gemm_n = gemm_ms + ms, gemm_n + n
         attn_ms += e.get_timing(2)[0]
         e.set_timing(False)
-    assert all(o.numel() == PROMPT_LEN + NEW_TOKENS for out in outs for o in out)
+    timed_prompts = [p for b in batches[n_warm:] for p in b]
+    assert all(o.numel() == p.numel() + NEW_TOKENS for o, p in zip([o for out in outs for o in out], timed_prompts))
     if world > 1:
         tt = torch.tensor([dt], device="cpu" if rehearsal else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -165,7 +171,7 @@ def main() -> None:
     result = None
     if rank == 0:
         utt = B * a.steps * world
-        flops = gemm_flops_per_prefill(cfg, B * PROMPT_LEN, B) * a.steps
+        flops = gemm_flops_per_prefill(cfg, sum(p.numel() for p in timed_prompts), B * a.steps)
         achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         traffic = None   # HBM-side bytes per launch from the committed PMC passes
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_gemm.json")
@@ -179,7 +185,7 @@ def main() -> None:
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "DualHyp inference, TinyLlama-1.1B bf16 + LoRA r16 (q,k,v,proj), batch 32/GPU "
                                    "synthetic 5+5-hyp prompts, 512-token prompt -> 64 generated tokens, greedy",
-                       "batch_per_gpu": B, "prompt_tokens": PROMPT_LEN, "new_tokens": NEW_TOKENS,
+                       "batch_per_gpu": B, "prompt_tokens": "uniform 384..640" if a.ragged else PROMPT_LEN, "new_tokens": NEW_TOKENS,
                        "parallelism": f"replicas x{world}", "batches_in_flight_per_gpu": G, "schedule": a.schedule,
                        "decode_rows_per_launch": B * min(G, a.steps) if a.schedule == "merged" else B,
                        "prefill_tokens_per_launch": B * PROMPT_LEN * (a.prefill_batches if a.schedule == "merged" else 1)},
@@ -195,7 +201,7 @@ def main() -> None:
         # launch plus each sequence's KV prefix; algorithmic bytes per step = 2.078 GB + rows x 22,528 B x S (S ~ 544)
         rows = phase["decode_row_steps"] / phase["decode_steps"]
         step_ms = phase["decode_ms"] / phase["decode_steps"]
-        step_bytes = 2 * (968_884_224 + 65_536_000 + 4_505_600) + rows * 22_528 * (PROMPT_LEN + NEW_TOKENS / 2)
+        step_bytes = 2 * (968_884_224 + 65_536_000 + 4_505_600) + rows * 22_528 * (sum(p.numel() for p in timed_prompts) / len(timed_prompts) + NEW_TOKENS / 2)
         result["phases"] = {"prefill_ms_per_step": phase["prefill_ms"] / a.steps, "decode_ms_per_step": phase["decode_ms"] / a.steps,
                             "decode_loop_ms_per_token": step_ms, "decode_rows_per_launch": rows}
         result["roofline_decode"] = {"bound": "hbm", "achieved": step_bytes / (step_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
@@ -216,7 +222,7 @@ def main() -> None:
         # batches jointly, so one engine's latency-bound decode loop runs under the other's prefills.  Higher
         # throughput, but the concurrent kernels time-slice the CUs and every per-kernel duration (hence a
         # roofline measured there) is inflated — which is why it is not the default schedule.
-        pipe = BatchPipeline(model, 2, B * G, PROMPT_LEN + NEW_TOKENS, B * PROMPT_LEN)
+        pipe = BatchPipeline(model, 2, B * G, max_len + NEW_TOKENS, B * max_len)
         flat = lambda bs: [p for b in bs for p in b]
         pipe.warm(flat([batches[0]] * G), NEW_TOKENS, prefill_batch=B, **gen_kw)
         reps = [batches[i % n_batches] for i in range(2 * G)]
