@@ -6,7 +6,7 @@ import sys, torch
 sys.path.insert(0, '.')
 from dualhyp_amd import ops
 D = "cuda:0"
-M, d, I, r = 32 * 512, 2048, 5632, 16
+M, d, I, r = 2 * 32 * 512, 2048, 5632, 16     # two batches per prefill launch, as bench.py runs
 g = torch.Generator(device=D).manual_seed(0)
 rn = lambda *s: (torch.randn(*s, device=D, generator=g) * 0.05).bfloat16()
 x, act = rn(M, d), rn(M, I)
