@@ -273,16 +273,14 @@ extern "C" int dh_attn_bwd_bf16(const dh_bf16* q, const dh_bf16* k, const dh_bf1
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = (size_t)qpk * 2 * (hs / 32) * 16 * 64 * sizeof(float);
     if (hs == 64) {
-        static bool attr = false;
-        if (!attr) { DH_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+        DH_MAX_LDS_ONCE(attn_bwd_dkdv_kernel<64>, 160 * 1024);
         hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64>), dim3(nt, n_groups, n_seq), dim3(64 * qpk), lds, s, q, k, v, dout, qT, doT,
                            lse, dsum, q_start, q_len, pad_start, dk, dv, n_head, n_groups, n_pad, scale);
         hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), dim3(nt, n_head, n_seq), dim3(64), 0, s, q, k, v, dout, kT, lse, dsum,
                            q_start, q_len, pad_start, dq, n_head, n_groups, n_pad, scale);
     } else {
         DH_CHECK(lds <= 160 * 1024, "dh_attn_bwd_bf16: too many heads per group for head_size 128");
-        static bool attr = false;
-        if (!attr) { DH_HIP(hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+        DH_MAX_LDS_ONCE(attn_bwd_dkdv_kernel<128>, 160 * 1024);
         hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128>), dim3(nt, n_groups, n_seq), dim3(64 * qpk), lds, s, q, k, v, dout, qT, doT,
                            lse, dsum, q_start, q_len, pad_start, dk, dv, n_head, n_groups, n_pad, scale);
         hipLaunchKernelGGL((attn_bwd_dq_kernel<128>), dim3(nt, n_head, n_seq), dim3(64), 0, s, q, k, v, dout, kT, lse, dsum,

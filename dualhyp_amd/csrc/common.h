@@ -1,6 +1,7 @@
 // Shared device/host helpers for libdualhyp_hip (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -99,3 +100,18 @@ void dh_set_error(const char* fmt, ...);
     } while (0)
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// hipFuncSetAttribute applies to the CURRENT device, and the launchers are entered from several host threads
+// (one engine per thread, dualhyp_amd/pipeline.py): remember per device that the attribute is set.  Two threads
+// racing on the first launch both set it, which is harmless.  `kernel` must be parenthesised if it contains commas.
+#define DH_MAX_LDS_ONCE(kernel, bytes)                                                                       \
+    do {                                                                                                     \
+        static std::atomic<uint64_t> _done{0};                                                               \
+        int _dev = 0;                                                                                        \
+        DH_HIP(hipGetDevice(&_dev));                                                                         \
+        const uint64_t _bit = 1ull << (_dev & 63);                                                           \
+        if (!(_done.load(std::memory_order_acquire) & _bit)) {                                               \
+            DH_HIP(hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
+            _done.fetch_or(_bit, std::memory_order_release);                                                 \
+        }                                                                                                    \
+    } while (0)

@@ -376,13 +376,9 @@ extern "C" int dh_attn_decode_fused_bf16(const float* qkv32, int n_part, int n_s
         else if (n_part <= 8) ATT_LAUNCH(64, 8);
         else ATT_LAUNCH(64, 16);
     } else {
-        static bool attr_set = false;
-        if (!attr_set) {
-            DH_HIP(hipFuncSetAttribute((const void*)attn_decode_fused_kernel<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_fused_lds<128>()));
-            DH_HIP(hipFuncSetAttribute((const void*)attn_decode_fused_kernel<128, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_fused_lds<128>()));
-            DH_HIP(hipFuncSetAttribute((const void*)attn_decode_fused_kernel<128, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_fused_lds<128>()));
-            attr_set = true;
-        }
+        DH_MAX_LDS_ONCE((attn_decode_fused_kernel<128, 2>), attn_fused_lds<128>());
+        DH_MAX_LDS_ONCE((attn_decode_fused_kernel<128, 8>), attn_fused_lds<128>());
+        DH_MAX_LDS_ONCE((attn_decode_fused_kernel<128, 16>), attn_fused_lds<128>());
         if (n_part <= 2) ATT_LAUNCH(128, 2);
         else if (n_part <= 8) ATT_LAUNCH(128, 8);
         else ATT_LAUNCH(128, 16);

@@ -46,7 +46,7 @@ struct dh_engine {
     hipStream_t gstream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_stage = nullptr;
     // captured decode steps, keyed by everything baked into the graph (a few batch sizes alternate in practice)
-    struct GKey { int64_t* tokens; int tok_ld; int32_t *length, *done; int n_seq, top_k; float temp; int64_t eos; uint64_t seed; };
+    struct GKey { int64_t* tokens; int tok_ld; int32_t *length, *done; int n_seq, top_k; float temp; int64_t eos; uint64_t seed; int rsqrt_vec; };
     struct GEntry { GKey key; hipGraphExec_t exec; uint64_t used; };
     std::vector<GEntry> graphs;
     uint64_t graph_clock = 0;
@@ -259,6 +259,7 @@ int head(dh_engine* e, const bf16_t* xrows, int rows, bf16_t* logits, const uint
 
 int decode_step(dh_engine* e, int64_t* tokens, int tok_ld, int32_t* length, int32_t* done, int n_seq, float temperature,
                 int top_k, int64_t eos_id, uint64_t seed, hipStream_t s);
+int engine_init(dh_engine* e, const dh_model_desc* desc, int max_batch, int s_max, int max_tokens);
 
 }  // namespace
 
@@ -272,6 +273,15 @@ extern "C" int dh_engine_create(const dh_model_desc* desc, int max_batch, int s_
     DH_CHECK(max_batch > 0 && max_tokens >= max_batch, "dh_engine_create: bad batch/token capacity");
     DH_CHECK(desc->rope_cos && desc->rope_sin && desc->wte && desc->ln_f && desc->lm_head && desc->h_layers, "dh_engine_create: null weight pointer");
     dh_engine* e = new dh_engine();
+    const int rc = engine_init(e, desc, max_batch, s_max, max_tokens);
+    if (rc) { dh_engine_destroy(e); return rc; }   // one cleanup path: nothing allocated so far leaks
+    *out = e;
+    return 0;
+}
+
+namespace {
+
+int engine_init(dh_engine* e, const dh_model_desc* desc, int max_batch, int s_max, int max_tokens) {
     e->d = *desc;
     e->layers.assign(desc->h_layers, desc->h_layers + desc->n_layer);
     e->d.h_layers = nullptr;
@@ -305,7 +315,7 @@ extern "C" int dh_engine_create(const dh_model_desc* desc, int max_batch, int s_
     rc |= dmalloc(e, &e->ones, (size_t)max_batch);
     const int64_t wb = dh_attn_decode_work_bytes(max_batch, H, hs, s_max);
     if (!rc) { hipError_t he = hipMalloc(&e->dec_work, wb); if (he != hipSuccess) rc = 2; e->dev_bytes += wb; }
-    if (rc) { dh_set_error("dh_engine_create: device allocation failed (%s)", dh_last_error()); dh_engine_destroy(e); return 2; }
+    if (rc) { dh_set_error("dh_engine_create: device allocation failed (%s)", dh_last_error()); return 2; }
     // the attention kernels rely on finite (zero) cache contents beyond the written positions
     DH_HIP(hipMemset(e->kc, 0, e->cache_layer_elems * desc->n_layer * sizeof(bf16_t)));
     DH_HIP(hipMemset(e->vtc, 0, e->cache_layer_elems * desc->n_layer * sizeof(bf16_t)));
@@ -318,9 +328,10 @@ extern "C" int dh_engine_create(const dh_model_desc* desc, int max_batch, int s_
     DH_HIP(hipEventCreateWithFlags(&e->ev_stage, hipEventDisableTiming));
     hipLaunchKernelGGL(iota_i32_kernel, dim3(cdiv(max_batch, 64)), dim3(64), 0, 0, e->seq_meta, max_batch);
     DH_HIP(hipDeviceSynchronize());
-    *out = e;
     return 0;
 }
+
+}  // namespace
 
 extern "C" void dh_engine_destroy(dh_engine* e) {
     if (!e) return;
@@ -481,12 +492,14 @@ extern "C" int dh_engine_decode(dh_engine* e, int64_t* tokens, int tok_ld, int32
     // staging buffer, so the call never waits for the stream (several engines can be driven back to back)
     hipLaunchKernelGGL(set_i32_kernel, dim3(1), dim3(1), 0, s, e->step_dev, (int32_t)first_step);
     DH_LAUNCH_CHECK();
-    const dh_engine::GKey key{tokens, tok_ld, length, done, n_seq, top_k, temperature, eos_id, seed};
+    // rsqrt_vec: `rt = rsqrt_vec > 0 ? flags : nullptr` is resolved while capturing, so it is part of the key
+    const dh_engine::GKey key{tokens, tok_ld, length, done, n_seq, top_k, temperature, eos_id, seed, e->rsqrt_vec};
     hipGraphExec_t gexec = nullptr;
     for (auto& g : e->graphs) {
         const dh_engine::GKey& k = g.key;
         if (k.tokens == key.tokens && k.tok_ld == key.tok_ld && k.length == key.length && k.done == key.done &&
-            k.n_seq == key.n_seq && k.top_k == key.top_k && k.temp == key.temp && k.eos == key.eos && k.seed == key.seed) {
+            k.n_seq == key.n_seq && k.top_k == key.top_k && k.temp == key.temp && k.eos == key.eos && k.seed == key.seed &&
+            k.rsqrt_vec == key.rsqrt_vec) {
             gexec = g.exec;
             g.used = ++e->graph_clock;
             break;

@@ -1,21 +1,27 @@
 // y[M,N] = epilogue(x[M,K] · W[N,K]^T) on the gfx950 matrix cores.
 //
 // Both operands are K-contiguous, so each MFMA fragment is one 16-byte run of a row.  The kernel
-// computes C^T tiles: the A operand is a 32-row slab of W (rows = n), the B operand a 32-row slab
-// of x (cols = m); a lane of the 32x32 accumulator then owns 4 consecutive n for one m, which
+// computes C^T tiles: the A operand is a 16-row slab of W (rows = n), the B operand a 16-row slab
+// of x (cols = m); a lane of the 16x16 accumulator then owns 4 consecutive n for one m, which
 // makes the epilogue (LoRA rank-16 update, SwiGLU pairing, adapter scale/bias, residual add) a
 // per-lane affair with 8-byte row-contiguous loads/stores.
 //
+// The MFMA shape (16x16x32) and the k order (one accumulator per output, k ascending in steps of 32)
+// are those of the 256-tile kernel (gemm256.hip): an output element goes through the SAME fp32 chain
+// whichever of the two tile sizes dh_linear_impl picks for the call, so a row's result does not depend
+// on how many other rows were packed into the launch (tests/test_hip_ops.py::test_linear_tile_size_invariant).
+//
 //   block  : 256 threads = 4 waves as 2(n) x 2(m); block tile 128(n) x 128(m), BK = 64
-//   wave   : 64 x 64 = 2 x 2 MFMA 32x32x16 tiles, 64 accumulator VGPRs
+//   wave   : 64 x 64 = 4 x 4 MFMA 16x16x32 tiles, 64 accumulator VGPRs
 //   LDS    : 2 stages x (W tile 16 KiB + x tile 16 KiB) = 64 KiB -> 2 blocks / CU
 //   staging: global_load_lds 16 B/lane (LDS image is lane-linear, so the bank swizzle
 //            chunk ^= (row>>1)&7 is applied to the SOURCE address and again on the ds_read)
 //   grid   : 1-D, remapped so each XCD (blocks b, b+8, ...) owns a contiguous band of tiles
 //
 // LoRA fused as a rank-16 epilogue (ger/lora.py:159-166, 388-402): xa = bf16(x·A^T) is computed
-// beforehand ([M,16*segments]); each 32x32 output tile then needs ONE extra MFMA
-// lacc = lora_B[32 n,16] · xa[32 m,16]^T, and y = bf16(bf16(acc) + bf16(bf16(lacc)*s)).
+// beforehand ([M,16*segments]); each 16x16 output tile then needs ONE extra MFMA (rank 16 zero-padded
+// to the instruction's K = 32) lacc = lora_B[16 n,16] · xa[16 m,16]^T, and
+// y = bf16(bf16(acc) + bf16(bf16(lacc)*s)).
 #include "common.h"
 #include "gemm.h"
 
@@ -63,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
             const bf16_t* base = a.w;
             int n;
             if (EPI == DH_EPI_SWIGLU) {
-                const int half = (row >> 5) & 1;  // 32-row MFMA tile parity: 0 = fc_1, 1 = fc_2
+                const int half = (row >> 5) & 1;  // 32-row halves of a wave's 64 rows: 0 = fc_1, 1 = fc_2
                 n = n0 + (row >> 6) * 32 + (row & 31);
                 base = half ? a.w2 : a.w;
             } else {
@@ -89,42 +95,36 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
         }
     };
 
-    f32x16 acc[2][2];
+    f32x4 acc[4][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // fragment read offsets (bytes) inside a tile; (row>>1)&7 only depends on the lane here
-    const int lr = lane & 31, lh = lane >> 5;
-    int offA[2], offB[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        offA[i] = (wn * 64 + i * 32 + lr) * 128;
-        offB[i] = (wm * 64 + i * 32 + lr) * 128;
-    }
-    const int sw = swz(lr);
+    // fragment read offsets (bytes) inside a tile: lane (frow, kg) reads row frow of a 16-row slab, the 16-byte
+    // chunk 4*ks + kg of its 128-byte row; (row>>1)&7 only depends on the lane here (slabs start at multiples of 16)
+    const int frow = lane & 15, kg = lane >> 4;
+    const int offA = (wn * 64 + frow) * 128, offB = (wm * 64 + frow) * 128;
+    const int sw = swz(frow);
 
     const int nk = a.K / BK;
     auto compute = [&](int buf) __attribute__((always_inline)) {
         const char* sA = smem + buf * 2 * TILE_BYTES;
         const char* sB = sA + TILE_BYTES;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int co = (((ks * 2 + lh) ^ sw) << 4);
-            bf16x8 fa[2], fb[2];
+        for (int ks = 0; ks < 2; ++ks) {
+            const int co = (((ks * 4 + kg) ^ sw) << 4);
+            bf16x8 fa[4], fb[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                fa[i] = *reinterpret_cast<const bf16x8*>(sA + offA[i] + co);
-                fb[i] = *reinterpret_cast<const bf16x8*>(sB + offB[i] + co);
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = *reinterpret_cast<const bf16x8*>(sA + offA + i * 2048 + co);
+                fb[i] = *reinterpret_cast<const bf16x8*>(sB + offB + i * 2048 + co);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
     };
     if constexpr (NST == 2) {
@@ -157,23 +157,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
     }
 
     // ---------------------------------------------------------------- epilogue
-    // accumulator element r of tile (i,j): n = nt + (r&3) + 8*(r>>2) + 4*lh ; m = mt + lr
+    // accumulator element r of tile (i,j): n = nt + 4*kg + r ; m = mt + frow
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int m = m0 + wm * 64 + j * 32 + lr;
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wm * 64 + j * 16 + frow;
         const bool m_ok = m < a.M;
         if (EPI == DH_EPI_SWIGLU) {
-            const int nt = n0 + wn * 32;
+            // the wave's 64 LDS rows are 32 rows of fc_1 (tiles 0,1) and the same 32 rows of fc_2 (tiles 2,3)
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int n = nt + 8 * rg + 4 * lh;
+            for (int i = 0; i < 2; ++i) {
+                const int n = n0 + wn * 32 + i * 16 + 4 * kg;
                 float o[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float g = rbf(acc[0][j][rg * 4 + e]);
-                    const float u = rbf(acc[1][j][rg * 4 + e]);
-                    const float s = rbf(g / (1.0f + expf(-g)));
-                    o[e] = s * u;
+                    const float g = rbf(acc[i][j][e]);
+                    const float u = rbf(acc[i + 2][j][e]);
+                    const float sg = rbf(g / (1.0f + expf(-g)));
+                    o[e] = sg * u;
                 }
                 if (m_ok && n < a.N) {
                     uint2 pk = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
@@ -182,48 +183,44 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int nt = n0 + wn * 64 + i * 32;
-                f32x16 lacc;
+            for (int i = 0; i < 4; ++i) {
+                const int nt = n0 + wn * 64 + i * 16;
+                const int n = nt + 4 * kg;
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rbf(acc[i][j][e]);
                 if (EPI == DH_EPI_LORA) {
                     const int seg = (nt >= a.split0) + (nt >= a.split1);
-                    int nn = nt + lr;
+                    int nn = nt + frow;
                     nn = nn < a.N ? nn : a.N - 1;
                     const int mm = m_ok ? m : a.M - 1;
-                    const bf16x8 lb = *reinterpret_cast<const bf16x8*>(a.lora_b + (size_t)nn * 16 + lh * 8);
-                    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(a.xa + (size_t)mm * a.xa_ld + seg * 16 + lh * 8);
+                    bf16x8 lb = zero8, xf = zero8;          // rank 16 zero-padded to the MFMA's K = 32
+                    if (kg < 2) {
+                        lb = *reinterpret_cast<const bf16x8*>(a.lora_b + (size_t)nn * 16 + kg * 8);
+                        xf = *reinterpret_cast<const bf16x8*>(a.xa + (size_t)mm * a.xa_ld + seg * 16 + kg * 8);
+                    }
+                    f32x4 lacc = {0.f, 0.f, 0.f, 0.f};
+                    lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lb, xf, lacc, 0, 0, 0);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
-                    lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lb, xf, lacc, 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) o[e] = rbf(o[e] + rbf(rbf(lacc[e]) * a.lora_scale));
                 }
+                if (!(m_ok && n < a.N)) continue;
+                if (EPI == DH_EPI_ADAPTER) {
+                    const uint2 sc = *reinterpret_cast<const uint2*>(a.vec_a + n);
+                    const uint2 bi = *reinterpret_cast<const uint2*>(a.vec_b + n);
+                    const bf16_t* sp = reinterpret_cast<const bf16_t*>(&sc);
+                    const bf16_t* bp = reinterpret_cast<const bf16_t*>(&bi);
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const int n = nt + 8 * rg + 4 * lh;
-                    if (!(m_ok && n < a.N)) continue;
-                    float o[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = rbf(acc[i][j][rg * 4 + e]);
-                    if (EPI == DH_EPI_LORA) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = rbf(o[e] + rbf(rbf(lacc[rg * 4 + e]) * a.lora_scale));
-                    }
-                    if (EPI == DH_EPI_ADAPTER) {
-                        const uint2 sc = *reinterpret_cast<const uint2*>(a.vec_a + n);
-                        const uint2 bi = *reinterpret_cast<const uint2*>(a.vec_b + n);
-                        const bf16_t* sp = reinterpret_cast<const bf16_t*>(&sc);
-                        const bf16_t* bp = reinterpret_cast<const bf16_t*>(&bi);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = rbf(bf2f(sp[e]) * rbf(o[e] + bf2f(bp[e])));
-                    }
-                    if (RESID) {
-                        const uint2 rr = *reinterpret_cast<const uint2*>(a.resid + (size_t)m * a.N + n);
-                        const bf16_t* rp = reinterpret_cast<const bf16_t*>(&rr);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = bf2f(rp[e]) + o[e];
-                    }
-                    uint2 pk = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
-                    *reinterpret_cast<uint2*>(a.y + (size_t)m * a.N + n) = pk;
+                    for (int e = 0; e < 4; ++e) o[e] = rbf(bf2f(sp[e]) * rbf(o[e] + bf2f(bp[e])));
                 }
+                if (RESID) {
+                    const uint2 rr = *reinterpret_cast<const uint2*>(a.resid + (size_t)m * a.N + n);
+                    const bf16_t* rp = reinterpret_cast<const bf16_t*>(&rr);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = bf2f(rp[e]) + o[e];
+                }
+                uint2 pk = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+                *reinterpret_cast<uint2*>(a.y + (size_t)m * a.N + n) = pk;
             }
         }
     }
@@ -232,11 +229,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
 template <int EPI, bool RESID, int NST>
 int launch_n(const GemmArgs& a, hipStream_t s) {
     constexpr int lds = NST * 2 * TILE_BYTES;
-    static bool attr = false;
-    if (!attr) {
-        DH_HIP(hipFuncSetAttribute((const void*)gemm_nt_kernel<EPI, RESID, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr = true;
-    }
+    DH_MAX_LDS_ONCE((gemm_nt_kernel<EPI, RESID, NST>), lds);
     hipLaunchKernelGGL((gemm_nt_kernel<EPI, RESID, NST>), dim3(a.nb_n * a.nb_m), dim3(256), lds, s, a);
     DH_LAUNCH_CHECK();
     return 0;

@@ -352,12 +352,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
 
 template <int EPI, bool RESID, int PIPE>
 int launch_one(const GemmArgs& a, hipStream_t s) {
-    static bool attr_set = false;
     auto kfn = gemm_nt256_kernel<EPI, RESID, PIPE>;
-    if (!attr_set) {
-        DH_HIP(hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_B));
-        attr_set = true;
-    }
+    DH_MAX_LDS_ONCE(kfn, 4 * TILE_B);
     hipLaunchKernelGGL(kfn, dim3(a.nb_n * a.nb_m), dim3(512), 4 * TILE_B, s, a);
     DH_LAUNCH_CHECK();
     return 0;

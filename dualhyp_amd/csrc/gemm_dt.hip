@@ -201,11 +201,7 @@ __global__ __launch_bounds__(256) void gemm_dt_kernel(DtArgs a) {
 template <int MODE, int NSTAGE>
 int launch_dt_n(const DtArgs& a, int blocks, hipStream_t s) {
     constexpr int lds = NSTAGE * STAGE;     // 128 KiB / 64 KiB
-    static bool attr = false;
-    if (!attr) {
-        DH_HIP(hipFuncSetAttribute((const void*)gemm_dt_kernel<MODE, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr = true;
-    }
+    DH_MAX_LDS_ONCE((gemm_dt_kernel<MODE, NSTAGE>), lds);
     hipLaunchKernelGGL((gemm_dt_kernel<MODE, NSTAGE>), dim3(blocks), dim3(256), lds, s, a);
     DH_LAUNCH_CHECK();
     return 0;

@@ -209,11 +209,7 @@ __global__ __launch_bounds__(640) void gemm_mid_kernel(GemmArgs a) {
 template <int EPI, int NG>
 int launch_mid(const GemmArgs& a, hipStream_t s) {
     constexpr int lds = NBUF * NG * 32 * XROW;
-    static bool attr = false;
-    if (!attr && lds > 48 * 1024) {
-        DH_HIP(hipFuncSetAttribute((const void*)gemm_mid_kernel<EPI, NG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr = true;
-    }
+    if (lds > 48 * 1024) DH_MAX_LDS_ONCE((gemm_mid_kernel<EPI, NG>), lds);
     dim3 grid(cdiv(a.N, 16 * MidShape<EPI>::RS), cdiv(a.M, NG * 32)), block(640);
     hipLaunchKernelGGL((gemm_mid_kernel<EPI, NG>), grid, block, lds, s, a);
     DH_LAUNCH_CHECK();

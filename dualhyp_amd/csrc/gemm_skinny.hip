@@ -340,11 +340,7 @@ int launch_rows(const bf16_t* x, const bf16_t* w, const bf16_t* w_ext, float* y3
     constexpr int NGL = NG * 32 * XS <= 144 * 1024 ? NG : NG / 2;   // groups resident in LDS at once
     constexpr int lds = NGL * 32 * XS;
     static_assert(lds <= 160 * 1024, "x slice does not fit in LDS");
-    static bool attr = false;
-    if (!attr && lds > 48 * 1024) {
-        DH_HIP(hipFuncSetAttribute((const void*)gemm_skinny_rows_kernel<KPS, NG, NGL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr = true;
-    }
+    if (lds > 48 * 1024) DH_MAX_LDS_ONCE((gemm_skinny_rows_kernel<KPS, NG, NGL>), lds);
     dim3 grid((N + 127) / 128, ksplit, cdiv(M, NG * 32)), block(512);
     hipLaunchKernelGGL((gemm_skinny_rows_kernel<KPS, NG, NGL>), grid, block, lds, s, x, w, w_ext, y32, M, n_main, N, K);
     DH_LAUNCH_CHECK();
@@ -437,8 +433,7 @@ extern "C" int dh_set_tuning(int key, int value) {
 
 int dh_linear_skinny(const GemmArgs& a, int epilogue, hipStream_t s) {
     if (epilogue == DH_EPI_SWIGLU && g_swiglu2 && a.N % 32 == 0) {
-        static bool attr = false;
-        if (!attr) { DH_HIP(hipFuncSetAttribute((const void*)swiglu_skinny2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); attr = true; }
+        DH_MAX_LDS_ONCE(swiglu_skinny2_kernel, 64 * 1024);
         hipLaunchKernelGGL(swiglu_skinny2_kernel, dim3(a.N / 32), dim3(512), 64 * 1024, s, a);
         DH_LAUNCH_CHECK();
         return 0;

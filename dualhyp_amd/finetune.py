@@ -54,10 +54,10 @@ def step_schedule(n_micro: int, accum: int, reference_accumulation: bool = False
     return out
 
 
-def epoch_order(n: int, epoch: int, rank: int, world: int, seed: int = 1337) -> List[int]:
+def epoch_order(n: int, epoch: int, rank: int, world: int, seed: int = 1337, shuffle: bool = True) -> List[int]:
     """This rank's utterances for one epoch: strided slice of a seeded permutation (same on every rank)."""
     g = torch.Generator().manual_seed(seed + epoch)
-    perm = torch.randperm(n, generator=g).tolist()
+    perm = torch.randperm(n, generator=g).tolist() if shuffle else list(range(n))
     usable = n - n % world                      # equal work per rank: drop the ragged tail
     return perm[rank:usable:world]
 
@@ -102,6 +102,7 @@ class TrainConfig:
     lm_head_chunk_size: int = 128
     save_interval: int = 0               # micro-iterations between validations; 0 = only at the end
     reference_accumulation: bool = False
+    shuffle: bool = True                 # False: utterances in file order (trajectory fixtures)
 
 
 def micro_loss(model, input_ids: torch.Tensor, labels: torch.Tensor, chunk: int) -> torch.Tensor:
@@ -133,8 +134,12 @@ from .checkpoint import save_checkpoint  # noqa: E402,F401  (finetune/ger.py:356
 
 def fit(model, train_examples: Sequence[Dict[str, torch.Tensor]], collate: Callable, cfg: TrainConfig, *,
         val_batches: Optional[Callable[[], Iterable[Dict[str, torch.Tensor]]]] = None, out_dir: Optional[str] = None,
-        rank: int = 0, world: int = 1, device="cuda", log: Callable[[str], None] = print) -> Dict[str, float]:
-    """Runs the fine-tune; returns {'final_train_loss', 'best_val_loss', 'optimizer_steps'}."""
+        rank: int = 0, world: int = 1, device="cuda", log: Callable[[str], None] = print,
+        on_step: Optional[Callable[[int, List[torch.nn.Parameter]], None]] = None,
+        on_micro: Optional[Callable[[int, torch.Tensor], None]] = None) -> Dict[str, float]:
+    """Runs the fine-tune; returns {'final_train_loss', 'best_val_loss', 'optimizer_steps'}.
+    `on_step(step_index, lora_parameters)` is called after every optimizer step, `on_micro(iteration, loss)` after
+    every micro-batch (tests, progress reporting); neither is needed for training."""
     from .train import prepare_for_training
     model.train()
     params = prepare_for_training(model)
@@ -147,7 +152,7 @@ def fit(model, train_examples: Sequence[Dict[str, torch.Tensor]], collate: Calla
     it, micro, steps, best_val, last = 0, 0, 0, float("inf"), float("nan")
     loss_acc = torch.zeros((), device=device)          # no per-micro-step .item(): one host sync per log line
     for epoch in range(cfg.num_epochs):
-        order = epoch_order(len(train_examples), epoch, rank, world)
+        order = epoch_order(len(train_examples), epoch, rank, world, shuffle=cfg.shuffle)
         for b0 in range(0, len(order) - cfg.micro_batch_size + 1, cfg.micro_batch_size):
             batch = collate([train_examples[i] for i in order[b0:b0 + cfg.micro_batch_size]])
             ids, labels = batch["input_ids"].to(device), batch["labels"].to(device)
@@ -156,6 +161,8 @@ def fit(model, train_examples: Sequence[Dict[str, torch.Tensor]], collate: Calla
             loss = micro_loss(model, ids, labels, cfg.lm_head_chunk_size)
             (loss / accum).backward()
             loss_acc += loss.detach()
+            if on_micro is not None:
+                on_micro(it, loss.detach())
             micro += 1
             hit = (micro + 1) % accum == 0 if cfg.reference_accumulation else micro % accum == 0
             if hit:
@@ -163,6 +170,8 @@ def fit(model, train_examples: Sequence[Dict[str, torch.Tensor]], collate: Calla
                 opt.step()
                 bucket.zero()
                 model.refresh_engine()
+                if on_step is not None:
+                    on_step(steps, params)
                 micro, steps = 0, steps + 1
             it += 1
             if cfg.save_interval and it % cfg.save_interval == 0:

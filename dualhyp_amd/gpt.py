@@ -405,10 +405,10 @@ class GPT(nn.Module):
         self.max_seq_length = config.block_size
         self.mask_cache: Optional[torch.Tensor] = None   # never built: causality is implicit in the kernels
         self.kv_caches: List[KVCache] = []                # kept for API parity; the engine owns the cache
-        # Lanes of torch's bf16 vector loop on the host whose CPU run of the reference is to be
-        # reproduced bit for bit (32 = AVX-512, 16 = AVX2); 0 = round rsqrt once, like a GPU run of
-        # the reference.  See dh_rmsnorm_bf16 / DESIGN.md Q11.
-        self.cpu_rsqrt_vec_width = 32
+        # 0 (the product default): RMSNorm rounds rsqrt once, as a GPU run of the reference does.  Tests that
+        # compare with the reference's CPU tensors set 32 (AVX-512 hosts; 16 = AVX2): torch's CPU bf16 rsqrt
+        # rounds twice in its scalar tail loop and dh_rmsnorm_bf16 can reproduce that per row.
+        self.cpu_rsqrt_vec_width = 0
         self._engine: Optional[_Engine] = None
         self._capacity = dict(max_batch=1, s_max=0, max_tokens=0)
         self._cache_len: List[int] = []                   # tokens currently valid per cache slot
@@ -508,9 +508,14 @@ class GPT(nn.Module):
             assert self.max_seq_length >= T, f"Cannot forward sequence of length {T}, max seq length is only {self.max_seq_length}"
         assert self.max_seq_length <= block_size, f"Cannot attend to {self.max_seq_length}, block size is only {block_size}"
         assert block_size >= T, f"Cannot forward sequence of length {T}, block size is only {block_size}"
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            from .train import forward_train  # autograd path (LoRA fine-tune)
-            return forward_train(self, idx, lm_head_chunk_size)
+        if not use_kv_cache and torch.is_grad_enabled():
+            # autograd path (LoRA fine-tune, finetune/ger.py:278): only the no-cache forward trains, and only
+            # when there is an active LoRA parameter asking for a gradient.  A cached call (input_pos given) is
+            # incremental decoding whatever the grad mode — the reference allows it outside no_grad() — and
+            # runs through the engine below, which returns logits without a graph.
+            from .train import forward_train, lora_parameters
+            if any(p.requires_grad for p in lora_parameters(self)):
+                return forward_train(self, idx, lm_head_chunk_size)
         if use_kv_cache:
             pos = input_pos.tolist() if input_pos.numel() <= 2 else [int(input_pos[0]), int(input_pos[-1])]
             p0 = pos[0]

@@ -32,6 +32,19 @@ def _dev(t: torch.Tensor, dtype=torch.bfloat16, name="tensor") -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+class _Keep(list):
+    """Pointer of a validated (contiguous, right dtype, on the GPU) view of `t`, with the view kept alive until the
+    wrapper returns: `.contiguous()` may allocate a temporary, and a temporary freed before the launch is enqueued
+    could be handed to the next argument by the caching allocator (two kernel arguments would then alias)."""
+
+    def __call__(self, t: Optional[torch.Tensor], dtype=torch.bfloat16, name: str = "tensor"):
+        if t is None:
+            return None
+        t = _dev(t, dtype, name)
+        self.append(t)
+        return t.data_ptr()
+
+
 def embed(ids: torch.Tensor, wte: torch.Tensor) -> torch.Tensor:
     ids = _dev(ids.reshape(-1), torch.int64, "ids")
     wte = _dev(wte, name="wte")
@@ -90,13 +103,14 @@ def qkv_rope_cache(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, tok_
                    n_groups: int, k_out: Optional[torch.Tensor] = None, v_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """-> rotated q [n_tok, n_head, hs]; appends k / v^T into the caches in place (and, for training,
     plain copies into k_out / v_out [n_tok, n_groups, hs])."""
+    k = _Keep()
     qkv = _dev(qkv, name="qkv")
     hs = k_cache.size(-1)
     s_max = k_cache.size(-2)
     n_tok = qkv.numel() // ((n_head + 2 * n_groups) * hs)
     q = torch.empty((n_tok, n_head, hs), dtype=torch.bfloat16, device=qkv.device)
-    check(_lib.load().dh_qkv_rope_cache_bf16(_p(qkv), _p(_dev(cos)), _p(_dev(sin)), _p(_dev(tok_slot, torch.int32)),
-                                             _p(_dev(tok_pos, torch.int32)), _p(q), _p(k_cache), _p(vT_cache), _p(k_out),
+    check(_lib.load().dh_qkv_rope_cache_bf16(_p(qkv), k(cos), k(sin), k(tok_slot, torch.int32),
+                                             k(tok_pos, torch.int32), _p(q), _p(k_cache), _p(vT_cache), _p(k_out),
                                              _p(v_out), n_tok, n_head, n_groups, hs, s_max, _stream()))
     return q
 
@@ -104,26 +118,28 @@ def qkv_rope_cache(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, tok_
 def attn_prefill(q: torch.Tensor, k_cache: torch.Tensor, vT_cache: torch.Tensor, seq_slot: torch.Tensor,
                  q_start: torch.Tensor, q_len: torch.Tensor, kv_pos0: torch.Tensor, max_q_len: int,
                  lse: Optional[torch.Tensor] = None) -> torch.Tensor:
+    k = _Keep()
     n_tok, n_head, hs = q.shape
     n_groups, s_max = k_cache.size(1), k_cache.size(2)
     y = torch.empty((n_tok, n_head * hs), dtype=torch.bfloat16, device=q.device)
     i32 = torch.int32
-    check(_lib.load().dh_attn_prefill_bf16(_p(_dev(q)), _p(k_cache), _p(vT_cache), _p(_dev(seq_slot, i32)),
-                                           _p(_dev(q_start, i32)), _p(_dev(q_len, i32)), _p(_dev(kv_pos0, i32)), _p(y), _p(lse),
+    check(_lib.load().dh_attn_prefill_bf16(k(q), _p(k_cache), _p(vT_cache), k(seq_slot, i32),
+                                           k(q_start, i32), k(q_len, i32), k(kv_pos0, i32), _p(y), _p(lse),
                                            seq_slot.numel(), int(max_q_len), n_head, n_groups, hs, s_max, _stream()))
     return y
 
 
 def attn_decode(q: torch.Tensor, k_cache: torch.Tensor, vT_cache: torch.Tensor, seq_slot: torch.Tensor,
                 kv_len: torch.Tensor) -> torch.Tensor:
+    k = _Keep()
     n_seq, n_head, hs = q.shape
     n_groups, s_max = k_cache.size(1), k_cache.size(2)
     lib = _lib.load()
     work = torch.empty(lib.dh_attn_decode_work_bytes(n_seq, n_head, hs, s_max), dtype=torch.uint8, device=q.device)
     y = torch.empty((n_seq, n_head * hs), dtype=torch.bfloat16, device=q.device)
     i32 = torch.int32
-    check(lib.dh_attn_decode_bf16(_p(_dev(q)), _p(k_cache), _p(vT_cache), _p(_dev(seq_slot, i32)),
-                                  _p(_dev(kv_len, i32)), _p(y), _p(work), n_seq, n_head, n_groups, hs, s_max, _stream()))
+    check(lib.dh_attn_decode_bf16(k(q), _p(k_cache), _p(vT_cache), k(seq_slot, i32),
+                                  k(kv_len, i32), _p(y), _p(work), n_seq, n_head, n_groups, hs, s_max, _stream()))
     return y
 
 
@@ -131,11 +147,12 @@ def sample(logits: torch.Tensor, tokens: torch.Tensor, length: torch.Tensor, don
            temperature: float = 1.0, top_k: Optional[int] = None, eos_id: Optional[int] = None, seed: int = 0,
            step: int = 0) -> None:
     """Append one token per sequence in place (tokens/length/done); see dh_sample_bf16."""
+    k = _Keep()
     logits = _dev(logits, name="logits")
     n_seq, vocab = logits.shape
     assert tokens.dtype == torch.int64 and tokens.is_contiguous() and tokens.size(0) == n_seq
-    check(_lib.load().dh_sample_bf16(_p(logits), vocab, _p(tokens), tokens.size(1), _p(_dev(length, torch.int32)),
-                                     _p(_dev(done, torch.int32)), n_seq, float(temperature),
+    check(_lib.load().dh_sample_bf16(_p(logits), vocab, _p(tokens), tokens.size(1), k(length, torch.int32),
+                                     k(done, torch.int32), n_seq, float(temperature),
                                      0 if top_k is None else int(top_k), -1 if eos_id is None else int(eos_id),
                                      int(seed) & ((1 << 64) - 1), int(step), _stream()))
 
@@ -151,10 +168,11 @@ def im2col3(x: torch.Tensor, ld: int, relu: bool = False) -> torch.Tensor:
 
 def pool_head(h: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, pool: int) -> torch.Tensor:
     """ReLU -> AvgPool1d(pool, ceil) -> Linear(H, 3) on h [B,T,H]; dh_pool_head_bf16."""
+    k = _Keep()
     h = _dev(h, name="h")
     B, T, H = h.shape
     out = torch.empty((B, (T + pool - 1) // pool, 3), dtype=torch.bfloat16, device=h.device)
-    check(_lib.load().dh_pool_head_bf16(_p(h), _p(_dev(w, name="w")), _p(_dev(bias, name="bias")), _p(out), B, T, H, int(pool),
+    check(_lib.load().dh_pool_head_bf16(_p(h), k(w, name="w"), k(bias, name="bias"), _p(out), B, T, H, int(pool),
                                         _stream()))
     return out
 
@@ -174,11 +192,12 @@ def cross_entropy_fwd(logits: torch.Tensor, targets: torch.Tensor) -> Tuple[torc
 
 def cross_entropy_bwd(logits: torch.Tensor, targets: torch.Tensor, lse: torch.Tensor, grad_row: torch.Tensor) -> torch.Tensor:
     """dlogits (same shape / dtype as logits); dh_cross_entropy_bwd."""
+    k = _Keep()
     lg = _dev(logits.reshape(-1, logits.size(-1)), logits.dtype, "logits")
     tg = _dev(targets.reshape(-1), torch.int64, "targets")
     out = torch.empty_like(lg)
-    check(_lib.load().dh_cross_entropy_bwd(_p(lg), int(lg.dtype == torch.float32), _p(tg), _p(_dev(lse, torch.float32, "lse")),
-                                           _p(_dev(grad_row, torch.float32, "grad_row")), _p(out), lg.size(0), lg.size(1),
+    check(_lib.load().dh_cross_entropy_bwd(_p(lg), int(lg.dtype == torch.float32), _p(tg), k(lse, torch.float32, "lse"),
+                                           k(grad_row, torch.float32, "grad_row"), _p(out), lg.size(0), lg.size(1),
                                            _stream()))
     return out.view(logits.shape)
 
@@ -209,11 +228,12 @@ def finish_norm(h32: torch.Tensor, d: int, x_resid: torch.Tensor, w_norm: torch.
                 lora_b: Optional[torch.Tensor] = None, lora_scale: float = 1.0,
                 row_tail: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """(x_out, xn_out) = LoRA finish + residual + RMSNorm of fp32 partials; dh_finish_norm_bf16."""
+    k = _Keep()
     n_part, rows, ld = h32.shape
     x_resid = _dev(x_resid, name="x_resid")
     x_out, xn_out = torch.empty_like(x_resid), torch.empty_like(x_resid)
     check(_lib.load().dh_finish_norm_bf16(_p(h32), n_part, rows, d, ld - d, _p(lora_b), float(lora_scale), _p(x_resid),
-                                          _p(_dev(w_norm)), _p(x_out), _p(xn_out), float(eps), _p(row_tail), _stream()))
+                                          k(w_norm), _p(x_out), _p(xn_out), float(eps), _p(row_tail), _stream()))
     return x_out, xn_out
 
 
@@ -221,13 +241,14 @@ def attn_decode_fused(qkv32: torch.Tensor, qkv_dim: int, lora_b: Optional[torch.
                       splits: Tuple[int, int], cos: torch.Tensor, sin: torch.Tensor, seq_slot: torch.Tensor,
                       kv_len: torch.Tensor, k_cache: torch.Tensor, vT_cache: torch.Tensor, n_head: int) -> torch.Tensor:
     """Decode-step attention sub-layer from fp32 qkv partials; dh_attn_decode_fused_bf16."""
+    k = _Keep()
     n_part, n_seq, ld = qkv32.shape
     n_groups, s_max, hs = k_cache.size(1), k_cache.size(2), k_cache.size(3)
     y = torch.empty((n_seq, n_head * hs), dtype=torch.bfloat16, device=qkv32.device)
     i32 = torch.int32
     check(_lib.load().dh_attn_decode_fused_bf16(_p(qkv32), n_part, n_seq, qkv_dim, ld - qkv_dim, _p(lora_b),
-                                                float(lora_scale), splits[0], splits[1], _p(_dev(cos)), _p(_dev(sin)),
-                                                _p(_dev(seq_slot, i32)), _p(_dev(kv_len, i32)), _p(k_cache), _p(vT_cache),
+                                                float(lora_scale), splits[0], splits[1], k(cos), k(sin),
+                                                k(seq_slot, i32), k(kv_len, i32), _p(k_cache), _p(vT_cache),
                                                 _p(y), n_head, n_groups, hs, s_max, _stream()))
     return y
 
@@ -250,33 +271,37 @@ def vcache_to_plain(vt: torch.Tensor) -> torch.Tensor:
 
 # ------------------------------------------------------------------------------------------ training backward
 def swiglu_fwd(g: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
+    k = _Keep()
     act = torch.empty_like(g)
-    check(_lib.load().dh_swiglu_fwd_bf16(_p(_dev(g)), _p(_dev(u)), _p(act), g.numel(), _stream()))
+    check(_lib.load().dh_swiglu_fwd_bf16(k(g), k(u), _p(act), g.numel(), _stream()))
     return act
 
 
 def swiglu_bwd(dact: torch.Tensor, g: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
+    k = _Keep()
     rows, I = g.shape
     out = torch.empty((rows, 2 * I), dtype=torch.bfloat16, device=g.device)
-    check(_lib.load().dh_swiglu_bwd_bf16(_p(_dev(dact)), _p(_dev(g)), _p(_dev(u)), _p(out), rows, I, _stream()))
+    check(_lib.load().dh_swiglu_bwd_bf16(k(dact), k(g), k(u), _p(out), rows, I, _stream()))
     return out
 
 
 def rmsnorm_bwd(dy: torch.Tensor, x: torch.Tensor, w: torch.Tensor, eps: float, dres: Optional[torch.Tensor] = None) -> torch.Tensor:
+    k = _Keep()
     d = x.size(-1)
     dx = torch.empty_like(x)
-    check(_lib.load().dh_rmsnorm_bwd_bf16(_p(_dev(dy)), _p(_dev(x)), _p(_dev(w)), _p(dres), _p(dx), x.numel() // d, d,
+    check(_lib.load().dh_rmsnorm_bwd_bf16(k(dy), k(x), k(w), k(dres, name="dres"), _p(dx), x.numel() // d, d,
                                           float(eps), _stream()))
     return dx
 
 
 def qkv_rope_bwd(dq: torch.Tensor, dk: torch.Tensor, dv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
                  tok_pos: torch.Tensor) -> torch.Tensor:
+    k = _Keep()
     n_tok, n_head, hs = dq.shape
     n_groups = dk.size(1)
     out = torch.empty((n_tok, (n_head + 2 * n_groups) * hs), dtype=torch.bfloat16, device=dq.device)
-    check(_lib.load().dh_qkv_rope_bwd_bf16(_p(_dev(dq)), _p(_dev(dk)), _p(_dev(dv)), _p(_dev(cos)), _p(_dev(sin)),
-                                           _p(_dev(tok_pos, torch.int32)), _p(out), n_tok, n_head, n_groups, hs, _stream()))
+    check(_lib.load().dh_qkv_rope_bwd_bf16(k(dq), k(dk), k(dv), k(cos), k(sin),
+                                           k(tok_pos, torch.int32), _p(out), n_tok, n_head, n_groups, hs, _stream()))
     return out
 
 
@@ -292,6 +317,7 @@ def tn_accum(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, scale: float =
 def attn_bwd(q, k, v, out, dout, lse, q_start, q_len, max_q_len: int, lens: Optional[Sequence[int]] = None):
     """-> (dq, dk, dv) of the causal GQA attention of a packed batch (sequences attend to themselves).
     `lens` = q_len on the host; when given nothing here touches the host (hipGraph capture of a training step)."""
+    keep = _Keep()
     n_tok, H, hs = q.shape
     G = k.size(1)
     lib = _lib.load()
@@ -304,16 +330,16 @@ def attn_bwd(q, k, v, out, dout, lse, q_start, q_len, max_q_len: int, lens: Opti
     tok_seq = torch.repeat_interleave(torch.arange(len(lens), dtype=torch.int32, device=dev), q_len.to(torch.int64), output_size=n_tok)
     dout = _dev(dout.reshape(n_tok, H, hs))
     dsum = torch.empty((n_tok, H), dtype=torch.float32, device=dev)
-    check(lib.dh_rowdot_f32(_p(dout), _p(_dev(out.reshape(n_tok, H, hs))), _p(dsum), n_tok * H, hs, _stream()))
+    check(lib.dh_rowdot_f32(_p(dout), keep(out.reshape(n_tok, H, hs)), _p(dsum), n_tok * H, hs, _stream()))
 
     def tpad(src, heads):
         dst = torch.zeros((heads, hs, n_pad), dtype=torch.bfloat16, device=dev)
-        check(lib.dh_transpose_pad_bf16(_p(_dev(src)), _p(dst), _p(tok_seq), _p(q_start), _p(pad_start), n_tok, heads, hs,
+        check(lib.dh_transpose_pad_bf16(keep(src), _p(dst), _p(tok_seq), _p(q_start), _p(pad_start), n_tok, heads, hs,
                                         n_pad, _stream()))
         return dst
     qT, doT, kT = tpad(q, H), tpad(dout, H), tpad(k, G)
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-    check(lib.dh_attn_bwd_bf16(_p(q), _p(k), _p(v), _p(dout), _p(qT), _p(doT), _p(kT), _p(lse), _p(dsum), _p(q_start),
+    check(lib.dh_attn_bwd_bf16(keep(q, name="q"), keep(k, name="k"), keep(v, name="v"), _p(dout), _p(qT), _p(doT), _p(kT), _p(lse), _p(dsum), _p(q_start),
                                _p(q_len), _p(pad_start), _p(dq), _p(dk), _p(dv), len(lens), int(max_q_len), H, G, hs,
                                n_pad, _stream()))
     return dq, dk, dv

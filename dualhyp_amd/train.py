@@ -331,12 +331,13 @@ class GraphedTrainStep:
         T = input_ids.size(1)
         T_pad = -(-T // self.pad_to) * self.pad_to
         dev = input_ids.device
-        ent = self._graphs.get(T_pad)
+        Vw = self.model.cpu_rsqrt_vec_width
+        gkey = (T_pad, Vw)        # the rsqrt-emulation switch is resolved while capturing: part of the key
+        ent = self._graphs.get(gkey)
         if ent is None:
             st = self._state(T_pad, dev)
-            ent = self._graphs[T_pad] = [st, None]
+            ent = self._graphs[gkey] = [st, None]
         st = ent[0]
-        Vw = self.model.cpu_rsqrt_vec_width
         st["ids"].zero_()
         st["ids"][0, :T].copy_(input_ids[0])
         st["targets"].fill_(-1)

@@ -15,6 +15,31 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# ---- parity record: every figure a GPU test measures against the reference's tensors (bit-exact fractions, ulp
+# maxima, relative RMS vs the fp32 yardstick, greedy-id prefix lengths) is collected here and written to
+# $DUALHYP_PARITY_JSON (default gpurun_out/parity.json) when the session ends; the committed copy is profiles/rNN_parity.json
+_PARITY = {}
+
+
+def record_parity(key: str, **figures) -> None:
+    _PARITY[key] = {k: (float(v) if isinstance(v, (int, float)) or hasattr(v, "__float__") else v) for k, v in figures.items()}
+    print(f"[parity] {key}: " + " ".join(f"{k}={v}" for k, v in _PARITY[key].items()))
+
+
+def pytest_sessionfinish(session, exitstatus):
+    import os
+    if not _PARITY:
+        return
+    path = Path(os.environ.get("DUALHYP_PARITY_JSON", REPO / "gpurun_out" / "parity.json"))
+    try:
+        path.parent.mkdir(parents=True, exist_ok=True)
+        old = json.loads(path.read_text()) if path.exists() else {}
+        old.update(_PARITY)
+        path.write_text(json.dumps(old, indent=1, sort_keys=True))
+    except OSError:
+        pass
+
+
 def load_golden(name: str):
     """-> (dict of tensors, meta dict) from tests/golden/<name>.safetensors."""
     from safetensors import safe_open

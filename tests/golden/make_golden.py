@@ -97,9 +97,12 @@ def ref_model(rlora, cfg_kwargs: dict, sd: dict, dtype):
     return m
 
 
-def cfg_kwargs_of(cfg) -> dict:
+def cfg_kwargs_of(cfg, relprompt: bool = False) -> dict:
     d = cfg.to_dict()
     d.pop("rope_n_elem", None)
+    if not relprompt:            # fields of ger.relprompt.Config only (ger/relprompt.py:117-119)
+        for k in ("whisper_dim", "raven_dim", "pool_size"):
+            d.pop(k, None)
     return d
 
 
@@ -315,6 +318,262 @@ def gen_full(rlora, rgenerate, name: str, seed: int, T: int, G: int) -> None:
     save(name, out, {"config": cfg_kwargs_of(cfg), "seed": seed, "T": T, "G": G})
 
 
+
+def _margins_teacher_forced(m, idx, g, T, G, keep_v=4096, fwd=None):
+    """Per-step logits of the reference's decode teacher-forced on its own ids `g`: top-2 margins (bf16 ulps),
+    the first `keep_v` vocabulary entries and the exact top-8 (value, index) of every step."""
+    fwd = fwd or (lambda x, pos: m(x, pos))
+    margins, first, top_v, top_i = [], [], [], []
+    with torch.no_grad():
+        lg = fwd(idx.view(1, -1), torch.arange(T))[0, -1]
+        for s in range(G):
+            margins.append(top2_margin_ulps(lg))
+            first.append(lg[:keep_v].clone())
+            v, i = torch.topk(lg.float(), 8)
+            top_v.append(v.to(lg.dtype)); top_i.append(i)
+            if s + 1 < G:
+                lg = fwd(g[T + s].view(1, 1), torch.tensor([T + s]))[0, 0]
+        m.reset_cache()
+    return torch.tensor(margins), torch.stack(first), torch.stack(top_v), torch.stack(top_i)
+
+
+def gen_full512(rlora, rgenerate, name: str, seed: int, T: int, G: int, head_peak: float, tries: int = 6) -> None:
+    """BASELINE config 2's own shape: the full 22-layer TinyLlama-1.1B, a T=512 prompt and G=64 generated
+    tokens by the reference's generate() (top_k=1, temperature 0.2).  lm_head.adapter_scale is heavy-tailed
+    (synth head_peak) so that the reference's arg-max is well separated on most steps; the prompt seed with
+    the longest tie-free prefix among `tries` candidates is kept (all candidates' statistics go into meta)."""
+    from dualhyp_amd.config import Config, GER_LORA
+    from dualhyp_amd.synth import synth_state_dict, synth_prompts
+
+    cfg = Config.from_name("tiny-llama-1.1b-chat", **{**GER_LORA, "dropout": 0.0})
+    sd = synth_state_dict(cfg, seed=seed, head_peak=head_peak)
+    m = ref_model(rlora, cfg_kwargs_of(cfg), sd, torch.bfloat16)
+    del sd
+    best, stats = None, []
+    for k in range(tries):
+        pseed = seed + k
+        idx = synth_prompts(1, T, cfg.padded_vocab_size, seed=pseed)[0]
+        torch.manual_seed(pseed)
+        g = rgenerate(m, idx, T + G, temperature=0.2, top_k=1, eos_id=None)
+        m.reset_cache()
+        mg, first, tv, ti = _margins_teacher_forced(m, idx, g, T, G)
+        unsafe = (mg < 4).nonzero().flatten().tolist()
+        safe = unsafe[0] if unsafe else G
+        stats.append({"prompt_seed": pseed, "safe_prefix": safe, "steps_margin_ge4": int((mg >= 4).sum()),
+                      "min_margin": float(mg.min()), "distinct_ids": int(g[T:].unique().numel())})
+        print(stats[-1], flush=True)
+        if best is None or safe > best[0]:
+            best = (safe, pseed, idx, g, mg, first, tv, ti)
+        if safe == G:
+            break
+    safe, pseed, idx, g, mg, first, tv, ti = best
+    out = {"idx": idx, "generate_ids": g, "generate_margins_ulps": mg, "step_logits_v4096": first,
+           "step_top8_values": tv, "step_top8_indices": ti}
+    del m
+    sd = synth_state_dict(cfg, seed=seed, head_peak=head_peak)
+    m32 = ref_model(rlora, cfg_kwargs_of(cfg), sd, torch.float32)
+    del sd
+    _, f32, tv32, ti32 = _margins_teacher_forced(m32, idx, g, T, G)
+    out["step_logits_fp32_v4096"] = f32
+    out["step_top8_values_fp32"], out["step_top8_indices_fp32"] = tv32, ti32
+    save(name, out, {"config": cfg_kwargs_of(cfg), "seed": seed, "prompt_seed": pseed, "T": T, "G": G,
+                     "head_peak": head_peak, "safe_prefix": safe, "candidates": stats})
+
+
+def gen_relprompt(rgenerate_unused, name: str, cfg_name: str, r: int, seed: int) -> None:
+    """BASELINE config 4's decoder: ger.relprompt.GPT (ger/relprompt.py:182-294) with the three reliability
+    tokens added to wte by resize_token_embeddings(3) (`:215-230`, inference/relprompt.py:341-342), a prompt that
+    contains ids V, V+1, V+2, no-cache logits, KV-cache prefill + decode steps and the greedy ids of
+    generate/relprompt.py's loop (`:31-102`).  The added rows are drawn by the reference with nn.init.normal_;
+    they are overwritten here with hash values ('transformer.wte.reliability_rows') so the fixture can be rebuilt."""
+    import ger.relprompt as rrel
+    from dualhyp_amd.config import Config
+    from dualhyp_amd.synth import synth_state_dict, synth_prompts, uniform, stream_id
+    try:
+        from generate.relprompt import generate as rel_generate
+    except Exception as e:  # its module-level imports need packages that are absent here
+        print(f"generate.relprompt not importable ({type(e).__name__}: {e}); using the loop over model.forward")
+        rel_generate = None
+
+    cfg = Config.from_name(cfg_name, r=r, alpha=2 * r, dropout=0.0, to_query=True, to_key=True, to_value=True,
+                           to_projection=True)
+    sd = synth_state_dict(cfg, seed=seed, norm_jitter=0.25, weight_scale=4.0)
+    V, d = cfg.padded_vocab_size, cfg.n_embd
+    extra = uniform((3, d), 0.02 * math.sqrt(3.0) * 4.0, stream_id(seed, "transformer.wte.reliability_rows"))
+    T, G = 28, 8
+    idx = synth_prompts(2, T, V, seed=seed)
+    for b in range(2):                                   # reliability tokens inside the prompt (one per 0.4 s chunk)
+        idx[b][5:11] = torch.tensor([V, V + 2, V + 1, V, V, V + 2])
+        idx[b][17:20] = torch.tensor([V + 1, V, V + 2])
+    out = {"idx0": idx[0], "idx1": idx[1], "wte_extra_rows": extra}
+    kw = cfg_kwargs_of(cfg, relprompt=True)
+    meta = {"config": kw, "seed": seed, "T": T, "G": G, "norm_jitter": 0.25, "weight_scale": 4.0}
+    for tag, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+        rcfg = rrel.Config(**kw)
+        m = rrel.GPT(rcfg)
+        cls_keys = [k for k in m.state_dict() if "noise_classifier" in k]
+        full = {k: v.to(dt) for k, v in sd.items()}
+        for k in cls_keys:                                # reliability predictors are not on this path
+            full[k] = torch.zeros_like(m.state_dict()[k]).to(dt)
+        m = m.to(dt)
+        m.load_state_dict(full, strict=True)
+        m.resize_token_embeddings(3)
+        assert m.transformer.wte.weight.shape[0] == V + 3
+        m.transformer.wte.weight.data[V:] = extra.to(dt)
+        m = m.to(dt).eval()
+        with torch.no_grad():
+            out[f"{tag}.logits_nocache"] = m(torch.stack(idx))
+            m.reset_cache()
+            lg = m(idx[0].view(1, -1), input_pos=torch.arange(T))
+            out[f"{tag}.logits_prefill"] = lg
+            toks, steps = [], []
+            nxt = int(lg[0, -1].float().argmax())
+            for s in range(3):
+                toks.append(nxt)
+                lg = m(torch.tensor([[nxt]]), input_pos=torch.tensor([T + s]))
+                steps.append(lg[0, 0])
+                nxt = int(lg[0, 0].float().argmax())
+            out[f"{tag}.decode_tokens"] = torch.tensor(toks)
+            out[f"{tag}.logits_decode"] = torch.stack(steps)
+            m.reset_cache()
+            torch.manual_seed(seed)
+            if rel_generate is not None:
+                g = rel_generate(m, None, None, None, None, idx[1], T + G, cfg.block_size, temperature=0.2, top_k=1, eos_id=None)
+            else:
+                g = idx[1].clone()
+                pos = torch.arange(T)
+                buf = torch.empty(T + G, dtype=torch.int64); buf[:T] = idx[1]
+                for _ in range(G):
+                    l_ = m(buf.index_select(0, pos).view(1, -1), input_pos=pos)[0, -1] / 0.2
+                    v_, _i = torch.topk(l_, 1)
+                    l_ = torch.where(l_ < v_[[-1]], -float("inf"), l_)
+                    nx = torch.multinomial(torch.softmax(l_, -1), 1)
+                    pos = pos[-1:] + 1
+                    buf = buf.index_copy(0, pos, nx)
+                g = buf
+            out[f"{tag}.generate_ids"] = g
+            m.reset_cache()
+            mg, _, _, _ = _margins_teacher_forced(m, idx[1], g, T, G, fwd=lambda x, pos: m(x, input_pos=pos))
+            out[f"{tag}.generate_margins_ulps"] = mg
+    meta["generate_loop"] = "generate/relprompt.py" if rel_generate is not None else "restated over ger.relprompt.GPT.forward"
+    save(name, out, meta)
+
+
+def _train_micro(rlora, rutils, m, ids, labels, chunk, accum, autocast):
+    import contextlib
+    ctx = torch.autocast("cpu", dtype=torch.bfloat16) if autocast else contextlib.nullcontext()
+    with ctx:
+        logits = m(ids, lm_head_chunk_size=chunk)
+        logits[-1] = logits[-1][..., :-1, :]
+        loss = rutils.chunked_cross_entropy(logits, labels[..., 1:], chunk_size=chunk)
+    (loss / accum).backward()
+    return loss.detach().float()
+
+
+def gen_train_shape(rlora, rutils, name: str, seed: int, T: int, n_layer: int) -> None:
+    """BASELINE config 3 at the TinyLlama layer SHAPE (d=2048, 32/4 heads, I=5632, V=32000, LoRA r=16), `n_layer`
+    layers, one micro-batch of T=560 tokens (512 prompt positions masked with -1, 47 response tokens + EOS):
+    loss and LoRA gradients of finetune/ger.py:278-285 in fp32, in bf16-true and under the reference's own
+    training precision, bf16-mixed (fp32 parameters + torch.autocast(bf16), ger/utils.py:475-489)."""
+    from dualhyp_amd.config import Config, GER_LORA
+    from dualhyp_amd.synth import synth_state_dict, synth_prompts
+    cfg = Config.from_name("tiny-llama-1.1b-chat", **{**GER_LORA, "dropout": 0.0, "n_layer": n_layer})
+    sd = synth_state_dict(cfg, seed=seed, norm_jitter=0.25)
+    ids = synth_prompts(1, T, cfg.padded_vocab_size, seed=seed)[0].view(1, -1)
+    labels = ids.clone()
+    labels[:, :512] = -1
+    out = {"input_ids": ids, "labels": labels}
+    for tag, dt, ac in (("fp32", torch.float32, False), ("bf16", torch.bfloat16, False), ("mixed", torch.float32, True)):
+        m = ref_model(rlora, cfg_kwargs_of(cfg), sd, dt)
+        m.train()
+        rlora.mark_only_lora_as_trainable(m)
+        out[f"{tag}.train_loss"] = _train_micro(rlora, rutils, m, ids, labels, 128, 32, ac)
+        for n, p in m.named_parameters():
+            if p.requires_grad:
+                out[f"{tag}.grad.{n}"] = p.grad.float() if tag == "fp32" else p.grad.to(torch.bfloat16)
+        print(tag, "loss", float(out[f"{tag}.train_loss"]), flush=True)
+        del m
+    save(name, out, {"config": cfg_kwargs_of(cfg), "seed": seed, "T": T, "norm_jitter": 0.25, "grad_accum": 32})
+
+
+def gen_adamw(rlora, rutils, name: str, cfg_name: str, r: int, seed: int) -> None:
+    """finetune/ger.py:126-133,255-292 on the tiny model: AdamW(lr 1e-4 peak, weight_decay 0.02) on the LoRA
+    parameters, linear warm-up (lr = peak * it / warmup), `loss / accum` accumulated over `accum` micro-batches of
+    one utterance, 3 optimizer steps.  The harness module cannot be imported, so the loop below is
+    a transcription of those lines around the REFERENCE's model, loss and torch.optim.AdamW; it stores the
+    micro-step losses and the LoRA parameters after every optimizer step, in fp32 and under bf16-mixed autocast."""
+    from dualhyp_amd.config import Config
+    from dualhyp_amd.synth import synth_state_dict, synth_prompts
+    cfg = Config.from_name(cfg_name, r=r, alpha=2 * r, dropout=0.0, to_query=True, to_key=True, to_value=True,
+                           to_projection=True)
+    sd = synth_state_dict(cfg, seed=seed, norm_jitter=0.25, weight_scale=4.0)
+    accum, n_steps, peak, warmup = 2, 3, 1e-2, 4
+    lens = [24, 31, 19, 27, 24, 22]
+    prompts = synth_prompts(accum * n_steps, 40, cfg.padded_vocab_size, seed=seed + 5)
+    out, meta = {}, {"config": cfg_kwargs_of(cfg), "seed": seed, "norm_jitter": 0.25, "weight_scale": 4.0, "accum": accum,
+                     "steps": n_steps, "lr": peak, "warmup_steps": warmup, "weight_decay": 0.02, "lens": lens}
+    for i, (p, n) in enumerate(zip(prompts, lens)):
+        out[f"ids{i}"] = p[:n]
+    for tag, ac in (("fp32", False), ("mixed", True)):
+        m = ref_model(rlora, cfg_kwargs_of(cfg), sd, torch.float32)
+        m.train()
+        rlora.mark_only_lora_as_trainable(m)
+        params = [p for p in m.parameters() if p.requires_grad]
+        opt = torch.optim.AdamW(params, lr=peak, weight_decay=0.02)
+        losses, it = [], 0
+        for step in range(n_steps):
+            opt.zero_grad()
+            for a in range(accum):
+                ids = out[f"ids{it}"].view(1, -1)
+                labels = ids.clone()
+                labels[:, : ids.size(1) - 9] = -1
+                lr = peak * it / warmup if it <= warmup else peak
+                for gk in opt.param_groups:
+                    gk["lr"] = lr
+                losses.append(_train_micro(rlora, rutils, m, ids, labels, 8, accum, ac))
+                it += 1
+            opt.step()
+            for n, p in m.named_parameters():
+                if p.requires_grad:
+                    out[f"{tag}.step{step}.{n}"] = p.detach().clone()
+        out[f"{tag}.losses"] = torch.stack(losses)
+        print(tag, "losses", [round(float(x), 4) for x in losses], flush=True)
+    save(name, out, meta)
+
+
+def gen_llama3_shape(rlora, rgenerate, name: str, seed: int, T: int, G: int, n_layer: int) -> None:
+    """BASELINE config 5's layer shape (Llama-3-8B, ger/config.py:801-818: d=4096, 32 heads / 8 groups, hs=128,
+    I=14336, V=128256) with `n_layer` layers, bf16 + fp32 yardstick: prefill logits (last 4 positions, first 4096
+    and last 256 vocabulary entries), decode steps, greedy ids with margins.  rope base stays 10000 (quirk Q1)."""
+    from dualhyp_amd.config import Config, GER_LORA
+    from dualhyp_amd.synth import synth_state_dict, synth_prompts
+    cfg = Config.from_name("Llama-3-8B", **{**GER_LORA, "dropout": 0.0, "n_layer": n_layer, "block_size": 4096})
+    sd = synth_state_dict(cfg, seed=seed, head_peak=0.5)
+    idx = synth_prompts(1, T, cfg.padded_vocab_size, seed=seed)[0]
+    out = {"idx": idx}
+    m = ref_model(rlora, cfg_kwargs_of(cfg), sd, torch.bfloat16)
+    torch.manual_seed(seed)
+    g = rgenerate(m, idx, T + G, temperature=0.2, top_k=1, eos_id=None)
+    m.reset_cache()
+    out["generate_ids"] = g
+    with torch.no_grad():
+        lg = m(idx.view(1, -1), torch.arange(T))[0]
+        out["prefill_logits_last4_v4096"] = lg[-4:, :4096].clone()
+        out["prefill_logits_last4_tail256"] = lg[-4:, -256:].clone()
+        m.reset_cache()
+    mg, first, tv, ti = _margins_teacher_forced(m, idx, g, T, G)
+    out.update({"generate_margins_ulps": mg, "step_logits_v4096": first, "step_top8_values": tv, "step_top8_indices": ti})
+    del m
+    m32 = ref_model(rlora, cfg_kwargs_of(cfg), sd, torch.float32)
+    with torch.no_grad():
+        lg = m32(idx.view(1, -1), torch.arange(T))[0]
+        out["prefill_logits_last4_v4096_fp32"] = lg[-4:, :4096].clone()
+        m32.reset_cache()
+    _, f32, _, _ = _margins_teacher_forced(m32, idx, g, T, G)
+    out["step_logits_fp32_v4096"] = f32
+    save(name, out, {"config": cfg_kwargs_of(cfg), "seed": seed, "T": T, "G": G, "head_peak": 0.5})
+
+
 def gen_misc(rutils, rprompts) -> None:
     """Host-logic pins: CE normalisations (Q5), LR schedule, accumulation trace (Q3), prompts."""
     torch.manual_seed(7)
@@ -423,6 +682,17 @@ def main() -> None:
         gen_block(rlora, rmodel, "block_tinyllama", "parity-block", seed=1337, T=16)
     if want("full") and not a.skip_full:
         gen_full(rlora, rgenerate, "full_tinyllama", seed=1337, T=48, G=12)
+    if want("relprompt"):
+        gen_relprompt(rgenerate, "relprompt_tiny", "parity-tiny", r=4, seed=2024)
+        gen_relprompt(rgenerate, "relprompt_hs128", "parity-hs128", r=16, seed=2025)
+    if want("adamw"):
+        gen_adamw(rlora, rutils, "adamw_tiny", "parity-tiny", r=4, seed=99)
+    if want("train_shape") and not a.skip_full:
+        gen_train_shape(rlora, rutils, "train_tinyllama_shape", seed=1337, T=560, n_layer=2)
+    if want("llama3") and not a.skip_full:
+        gen_llama3_shape(rlora, rgenerate, "llama3_shape", seed=1337, T=96, G=12, n_layer=2)
+    if want("full512") and not a.skip_full:
+        gen_full512(rlora, rgenerate, "full_tinyllama_512", seed=1337, T=512, G=64, head_peak=0.5)
 
 
 if __name__ == "__main__":

@@ -106,6 +106,37 @@ def test_linear_lora(dev, M, d, r):
     check_ulp(got, want, 2, 0.002, "proj lora + resid")
 
 
+def test_linear_tile_size_invariant(dev):
+    """dh_linear_impl sends a prompt that runs alone (M = 512) to the 128-tile kernel and the same rows packed with
+    31 others (M = 16384) to the 256-tile kernel.  Both use mfma 16x16x32 with one accumulator per output and k
+    ascending in steps of 32, so a row must come out bit-identical either way — for every epilogue the prefill uses."""
+    from dualhyp_amd import ops
+    d, I, big, small, m0 = 2048, 5632, 16384, 512, 7 * 512
+    x = U((big, d), 1.0, "tx").to(dev)
+    xs = x[m0:m0 + small].contiguous()
+    w = U((2560, d), 0.05, "tw").to(dev)
+    assert torch.equal(ops.linear(x, w)[m0:m0 + small], ops.linear(xs, w)), "PLAIN: 128-tile and 256-tile kernels differ"
+    r = U((big, 2560), 1.0, "tr").to(dev)
+    assert torch.equal(ops.linear(x, w, resid=r)[m0:m0 + small], ops.linear(xs, w, resid=r[m0:m0 + small].contiguous()))
+    A48, B16 = U((48, d), 1 / math.sqrt(d), "ta").to(dev), U((2560, 16), 0.05, "tb").to(dev)
+    xa = ops.linear(x, A48)
+    xas = ops.linear(xs, A48)
+    assert torch.equal(xa[m0:m0 + small], xas)
+    kw = dict(epilogue=ops.EPI_LORA, lora_b=B16, lora_scale=2.0, splits=(2048, 2304))
+    assert torch.equal(ops.linear(x, w, xa=xa, **kw)[m0:m0 + small], ops.linear(xs, w, xa=xas, **kw)), "LORA differs"
+    w1, w2 = U((I, d), 0.05, "t1").to(dev), U((I, d), 0.05, "t2").to(dev)
+    assert torch.equal(ops.linear(x, w1, epilogue=ops.EPI_SWIGLU, w2=w2)[m0:m0 + small],
+                       ops.linear(xs, w1, epilogue=ops.EPI_SWIGLU, w2=w2)), "SWIGLU differs"
+    act = U((big, I), 1.0, "tact").to(dev)
+    wp = U((d, I), 0.05, "tp").to(dev)
+    rr = U((big, d), 1.0, "trr").to(dev)
+    assert torch.equal(ops.linear(act, wp, resid=rr)[m0:m0 + small],
+                       ops.linear(act[m0:m0 + small].contiguous(), wp, resid=rr[m0:m0 + small].contiguous())), "K = 5632 differs"
+    # a ragged tail: M not a multiple of either tile
+    xt = x[: 16384 - 77].contiguous()
+    assert torch.equal(ops.linear(xt, w)[-300:], ops.linear(xt[-300:].contiguous(), w))
+
+
 @pytest.mark.parametrize("M,d,I", [(50, 256, 384), (200, 2048, 5632), (300, 256, 384), (515, 2048, 5632)])
 def test_linear_swiglu_and_adapter(dev, M, d, I):
     from dualhyp_amd import ops

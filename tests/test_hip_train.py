@@ -6,6 +6,7 @@ import math
 import pytest
 import torch
 
+from conftest import record_parity
 from dualhyp_amd.synth import uniform, stream_id
 
 pytestmark = pytest.mark.gpu
@@ -148,6 +149,7 @@ def test_train_micro_step_matches_reference(golden, name):
     sd = synth_state_dict(cfg, seed=meta["seed"], norm_jitter=meta["norm_jitter"], weight_scale=meta["weight_scale"], device=DEV)
     m = GPT(cfg).to(device=DEV, dtype=torch.bfloat16)
     m.load_state_dict(sd)
+    m.cpu_rsqrt_vec_width = 32        # the golden is a CPU run of the reference (Q11)
     m.train()
     params = prepare_for_training(m)
     assert all(p.dtype == torch.float32 and p.requires_grad for p in params)
@@ -173,7 +175,7 @@ def test_train_micro_step_matches_reference(golden, name):
         worst = max(worst, e_hip)
         # HIP's distance to the exact (fp32) gradient within 2x the reference-bf16 run's own, or 3% of max
         assert e_hip <= max(2.0 * e_ref, 0.03), f"{n}: hip {e_hip:.3f} vs reference-bf16 {e_ref:.3f} of max|g|"
-    print(f"[parity] {name} LoRA grads: worst distance to fp32 reference {worst:.3%} of max|g|")
+    record_parity(f"{name}.lora_grads", worst_dist_to_fp32_over_max_g=worst, loss=loss.item(), ref_loss_bf16=ref_loss, ref_loss_fp32=f32_loss)
     # eval-mode forward under no_grad still goes through the engine
     m.eval()
     with torch.no_grad():
@@ -246,3 +248,94 @@ def test_fit_reduces_loss_and_saves_reference_checkpoint(tmp_path):
     # the LoRA masters moved, the frozen base did not
     assert not torch.equal(ck["model"]["transformer.h.0.attn.proj.lora_B"].float(), sd["transformer.h.0.attn.proj.lora_B"].float().cpu())
     assert torch.equal(ck["model"]["transformer.h.0.mlp.fc_1.linear.weight"], sd["transformer.h.0.mlp.fc_1.linear.weight"].cpu())
+
+
+def test_train_micro_step_tinyllama_shape(golden):
+    """BASELINE config 3 at the TinyLlama layer shape (d 2048, 32/4 heads, I 5632, V 32000, LoRA r 16; 2 layers),
+    one micro-batch of T = 560 tokens (512 prompt positions masked, 47 response tokens + EOS): loss and every LoRA
+    gradient of finetune/ger.py:278-285 against what the REFERENCE's autograd produced in fp32, in bf16-true and under
+    its own training precision bf16-mixed (fp32 parameters + autocast).  HIP keeps activations in bf16 and LoRA
+    masters in fp32: its distance to the fp32 gradient must stay within 2x that of the reference's own bf16-true and
+    bf16-mixed runs (whichever is larger)."""
+    from dualhyp_amd import GPT, Config, chunked_cross_entropy
+    from dualhyp_amd.synth import synth_state_dict
+    from dualhyp_amd.train import prepare_for_training
+    t, meta = golden("train_tinyllama_shape")
+    cfg = Config(**meta["config"])
+    sd = synth_state_dict(cfg, seed=meta["seed"], norm_jitter=meta["norm_jitter"], device=DEV)
+    m = GPT(cfg).to(device=DEV, dtype=torch.bfloat16)
+    m.load_state_dict(sd)
+    m.cpu_rsqrt_vec_width = 32
+    m.train()
+    prepare_for_training(m)
+    ids, labels = t["input_ids"].to(DEV), t["labels"].to(DEV)
+    logits = m(ids, lm_head_chunk_size=128)
+    assert len(logits) == 5 and logits[0].shape == (1, 128, 32000)
+    logits[-1] = logits[-1][..., :-1, :]
+    loss = chunked_cross_entropy(logits, labels[..., 1:], chunk_size=128)
+    (loss / meta["grad_accum"]).backward()
+    l32, lbf, lmx = (t[f"{k}.train_loss"].float().item() for k in ("fp32", "bf16", "mixed"))
+    assert abs(loss.item() - l32) <= max(2 * abs(lbf - l32), 2 * abs(lmx - l32), 5e-3), (loss.item(), l32, lbf, lmx)
+    worst = {"hip": 0.0, "bf16": 0.0, "mixed": 0.0}
+    for n, p in m.named_parameters():
+        if "lora_" not in n:
+            continue
+        g32 = t[f"fp32.grad.{n}"].float()
+        scale = g32.abs().max().item()
+        e = {"hip": (p.grad.float().cpu() - g32).abs().max().item() / scale,
+             "bf16": (t[f"bf16.grad.{n}"].float() - g32).abs().max().item() / scale,
+             "mixed": (t[f"mixed.grad.{n}"].float() - g32).abs().max().item() / scale}
+        for k in worst:
+            worst[k] = max(worst[k], e[k])
+        assert e["hip"] <= max(2.0 * max(e["bf16"], e["mixed"]), 0.03), f"{n}: {e}"
+    record_parity("train_tinyllama_shape.lora_grads", loss_hip=loss.item(), loss_fp32=l32, loss_bf16=lbf, loss_mixed=lmx,
+                  worst_hip=worst["hip"], worst_ref_bf16=worst["bf16"], worst_ref_mixed=worst["mixed"])
+
+
+def test_adamw_trajectory_matches_reference(golden):
+    """Three optimizer steps of the fine-tune loop (AdamW lr/weight-decay, warm-up schedule, accumulation over 2
+    micro-batches of one utterance; finetune/ger.py:126-133,255-292) through dualhyp_amd.finetune.fit against the
+    trajectory produced around the REFERENCE's model (tests/golden/adamw_tiny: fp32 and bf16-mixed).  Adam's first
+    steps move every element by ~lr whatever the gradient's size, so the yardstick is the distance between the
+    reference's own two precisions, relative to the size of the update."""
+    from dualhyp_amd import GPT, Config
+    from dualhyp_amd.data import collate
+    from dualhyp_amd.finetune import TrainConfig, fit
+    from dualhyp_amd.synth import synth_state_dict
+    t, meta = golden("adamw_tiny")
+    cfg = Config(**meta["config"])
+    sd = synth_state_dict(cfg, seed=meta["seed"], norm_jitter=meta["norm_jitter"], weight_scale=meta["weight_scale"], device=DEV)
+    m = GPT(cfg).to(device=DEV, dtype=torch.bfloat16)
+    m.load_state_dict(sd)
+    m.cpu_rsqrt_vec_width = 32
+    n = meta["accum"] * meta["steps"]
+    exs = []
+    for i in range(n):
+        ids = t[f"ids{i}"]
+        lab = ids.clone()
+        lab[: ids.numel() - 9] = -1
+        exs.append({"input_ids": ids, "labels": lab, "input_ids_no_response": ids[:-9], "input": "", "uid": str(i), "ground_truth": ""})
+    # warm-up = int(epoch_size * warmup_frac) // world = int(6 * 0.7) = 4 iterations, as the fixture's loop
+    tc = TrainConfig(learning_rate=meta["lr"], weight_decay=meta["weight_decay"], num_epochs=1, batch_size=meta["accum"],
+                     micro_batch_size=1, warmup_frac=0.7, lm_head_chunk_size=8, shuffle=False)
+    snaps, losses = [], []
+    names = [k for k, _ in m.named_parameters() if "lora_" in k]
+    fit(m, exs, collate, tc, device=DEV, log=lambda s: None,
+        on_step=lambda step, ps: snaps.append({k: p.detach().float().cpu().clone() for k, p in m.named_parameters() if "lora_" in k}),
+        on_micro=lambda it, loss: losses.append(loss.float().item()))
+    assert len(snaps) == meta["steps"] and len(losses) == n
+    l32, lmx = t["fp32.losses"], t["mixed.losses"]
+    for i, l in enumerate(losses):
+        assert abs(l - l32[i].item()) <= max(3 * abs(lmx[i].item() - l32[i].item()), 3e-2), (i, l, l32[i].item(), lmx[i].item())
+    base = {k: v.float().cpu() for k, v in sd.items() if "lora_" in k}
+    for step, snap in enumerate(snaps):
+        num_h = num_m = den = 0.0
+        for k in names:
+            a, mx = t[f"fp32.step{step}.{k}"], t[f"mixed.step{step}.{k}"]
+            num_h += (snap[k] - a).pow(2).sum().item()
+            num_m += (mx - a).pow(2).sum().item()
+            den += (a - base[k]).pow(2).sum().item()
+        rh, rm = (num_h / den) ** 0.5, (num_m / den) ** 0.5
+        record_parity(f"adamw_tiny.step{step}", rel_rms_hip_vs_fp32=rh, rel_rms_mixed_vs_fp32=rm, loss_hip=losses[2 * step + 1],
+                      loss_fp32=l32[2 * step + 1].item())
+        assert rh <= max(2.0 * rm, 0.1), f"step {step}: HIP parameters {rh:.3f} of the update away from the fp32 trajectory, bf16-mixed {rm:.3f}"
