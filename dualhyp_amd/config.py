@@ -198,6 +198,11 @@ configs.append(_llama(name="parity-hs128", hf_config=dict(org="dualhyp_amd", nam
                       block_size=256, vocab_size=512, padding_multiple=64, n_layer=2, n_head=4,
                       n_embd=512, intermediate_size=768, n_query_groups=2))
 
+# room for a byte-tokenised DualHyp prompt (~700 tokens) + 150 generated: harness tests (tests/test_harness.py)
+configs.append(_llama(name="parity-harness", hf_config=dict(org="dualhyp_amd", name="parity-harness"),
+                      block_size=1024, vocab_size=300, padding_multiple=64, n_layer=2, n_head=4,
+                      n_embd=256, intermediate_size=384, n_query_groups=2))
+
 name_to_config = {c["name"]: c for c in configs}
 
 # LoRA settings used by both reference harnesses (inference/ger.py:145-153, finetune/ger.py:386-394)

@@ -22,6 +22,10 @@ struct Timing {
 }  // namespace
 
 constexpr int MAX_DECODE_ROWS = 2048;  // single-token calls up to here take the 7-launch streaming path
+// Single-token steps over at least this many rows run the layer on the TILED MFMA GEMMs of the prefill (natural
+// k order) instead of the K-sliced streaming kernels: from a few hundred rows on the step is no longer weight-
+// bandwidth-bound and the partial-sum traffic of the K slices dominates (dh_set_tuning key 10; 0 = never).
+int g_decode_tiled_rows = 0;
 
 struct dh_engine {
     dh_model_desc d;
@@ -46,7 +50,7 @@ struct dh_engine {
     hipStream_t gstream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_stage = nullptr;
     // captured decode steps, keyed by everything baked into the graph (a few batch sizes alternate in practice)
-    struct GKey { int64_t* tokens; int tok_ld; int32_t *length, *done; int n_seq, top_k; float temp; int64_t eos; uint64_t seed; int rsqrt_vec; };
+    struct GKey { int64_t* tokens; int tok_ld; int32_t *length, *done; int n_seq, top_k; float temp; int64_t eos; uint64_t seed; int rsqrt_vec, tiled_rows; };
     struct GEntry { GKey key; hipGraphExec_t exec; uint64_t used; };
     std::vector<GEntry> graphs;
     uint64_t graph_clock = 0;
@@ -54,6 +58,7 @@ struct dh_engine {
     int slot_base = 0;         // first KV-cache slot of the sequences of the current forward call
     bool capturing = false;   // no event records inside a stream capture
     bool phase_decode = false; // single-token-per-sequence call: weight-streaming GEMMs + split-KV attention
+    bool decode_tiled = false; // ... except that this step's row count put it in the tiled class (g_decode_tiled_rows)
     Timing tm;
 };
 
@@ -116,7 +121,7 @@ int linear(dh_engine* e, const bf16_t* x, const bf16_t* w, bf16_t* y, int M, int
            const bf16_t* w2, const bf16_t* xa, int xa_ld, const bf16_t* lb, int s0, int s1, const bf16_t* va,
            const bf16_t* vb, const bf16_t* resid, hipStream_t s, bool timed) {
     // kernel choice is a property of the phase, never of the packing (batch invariance)
-    const int kernel = e->phase_decode ? 2 : 1;
+    const int kernel = e->phase_decode && !e->decode_tiled ? 2 : 1;
     if (timed) {
         TimeScope t(e, e->phase_decode ? 1 : 0, s);
         return dh_linear_impl(x, w, y, M, N, K, epi, w2, xa, xa_ld, lb, e->d.lora_scale, s0, s1, va, vb, resid, kernel, s);
@@ -429,7 +434,8 @@ extern "C" int dh_engine_forward_at(dh_engine* e, const int64_t* ids, const int3
     DH_HIP(hipEventRecord(e->ev_stage, s));
     int rc;
     // one token per sequence == a decode step (what generate()'s loop issues): same kernels as dh_engine_decode
-    const bool fast = max_q == 1 && n_seq <= MAX_DECODE_ROWS && e->d.n_embd % 16 == 0;
+    e->decode_tiled = max_q == 1 && g_decode_tiled_rows > 0 && n_seq >= g_decode_tiled_rows;
+    const bool fast = max_q == 1 && n_seq <= MAX_DECODE_ROWS && e->d.n_embd % 16 == 0 && !e->decode_tiled;
     if (fast) {
         if ((rc = run_layers_decode(e, ids, n_seq, e->row_tail, s))) return rc;
         e->last_ntok = n_tok;
@@ -465,7 +471,8 @@ int decode_step(dh_engine* e, int64_t* tokens, int tok_ld, int32_t* length, int3
                        e->tok_slot, e->tok_pos, kv_len, e->step_dev, n_seq, e->s_max);
     DH_LAUNCH_CHECK();
     int rc;
-    if (n_seq <= MAX_DECODE_ROWS) {
+    e->decode_tiled = g_decode_tiled_rows > 0 && n_seq >= g_decode_tiled_rows;
+    if (n_seq <= MAX_DECODE_ROWS && !e->decode_tiled) {
         if ((rc = run_layers_decode(e, e->dec_ids, n_seq, e->ones, s))) return rc;
         if ((rc = head_normed(e, n_seq, e->logits, s))) return rc;
     } else {
@@ -493,13 +500,13 @@ extern "C" int dh_engine_decode(dh_engine* e, int64_t* tokens, int tok_ld, int32
     hipLaunchKernelGGL(set_i32_kernel, dim3(1), dim3(1), 0, s, e->step_dev, (int32_t)first_step);
     DH_LAUNCH_CHECK();
     // rsqrt_vec: `rt = rsqrt_vec > 0 ? flags : nullptr` is resolved while capturing, so it is part of the key
-    const dh_engine::GKey key{tokens, tok_ld, length, done, n_seq, top_k, temperature, eos_id, seed, e->rsqrt_vec};
+    const dh_engine::GKey key{tokens, tok_ld, length, done, n_seq, top_k, temperature, eos_id, seed, e->rsqrt_vec, g_decode_tiled_rows};
     hipGraphExec_t gexec = nullptr;
     for (auto& g : e->graphs) {
         const dh_engine::GKey& k = g.key;
         if (k.tokens == key.tokens && k.tok_ld == key.tok_ld && k.length == key.length && k.done == key.done &&
             k.n_seq == key.n_seq && k.top_k == key.top_k && k.temp == key.temp && k.eos == key.eos && k.seed == key.seed &&
-            k.rsqrt_vec == key.rsqrt_vec) {
+            k.rsqrt_vec == key.rsqrt_vec && k.tiled_rows == key.tiled_rows) {
             gexec = g.exec;
             g.used = ++e->graph_clock;
             break;

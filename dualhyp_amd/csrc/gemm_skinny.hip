@@ -427,6 +427,7 @@ extern "C" int dh_set_tuning(int key, int value) {
     if (key == 7 && value >= 1) { g_chain_min_rows = value; return 0; }
     if (key == 8) { extern int g_dt_stages; g_dt_stages = value; return 0; }
     if (key == 9) { extern int g_gemm128_stages; g_gemm128_stages = value; return 0; }
+    if (key == 10 && value >= 0) { extern int g_decode_tiled_rows; g_decode_tiled_rows = value; return 0; }
     dh_set_error("dh_set_tuning: unknown key %d", key);
     return 1;
 }

@@ -85,7 +85,12 @@ class FlatGradBucket:
     def all_reduce_mean(self) -> None:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            if dist.get_backend() == "gloo" and self.flat.is_cuda:      # rehearsal on one GPU: stage through the host
+                host = self.flat.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                self.flat.copy_(host)
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)        # RCCL over xGMI: one 18 MB bucket
             self.flat.div_(dist.get_world_size())
 
 
@@ -193,3 +198,121 @@ def fit(model, train_examples: Sequence[Dict[str, torch.Tensor]], collate: Calla
     if out_dir and rank == 0:
         save_checkpoint(model, Path(out_dir) / "lit_model_lora_finetuned.pth")
     return {"final_train_loss": last, "best_val_loss": best_val, "optimizer_steps": steps}
+
+
+# ------------------------------------------------------------------------------------------ harness
+def main(argv: Optional[Sequence[str]] = None) -> Dict[str, float]:
+    """`python -m dualhyp_amd.finetune --train_path train.json --val_path val.json --dual_hypotheses --prompts_format
+    DualHyp --micro_batch_size 1 --lr 1e-4 --num_epochs 5` — the flags of finetune/ger.py:373-407.  Base weights come
+    from `<llm_checkpoint>/lit_model.pth` (finetune/ger.py:113,122-124); `--d N` trains data-parallel on N GPUs, one
+    process each, with one RCCL all-reduce of the flat LoRA-gradient bucket per optimizer step."""
+    import argparse
+    import json
+    import logging
+    import os
+    import random
+    import time
+    from .inference import add_lora_arguments, config_from_args, init_distributed
+    p = argparse.ArgumentParser(prog="python -m dualhyp_amd.finetune")
+    p.add_argument("--train_path", type=str, nargs="+", required=True)
+    p.add_argument("--val_path", type=str, default=None)
+    p.add_argument("--exp_name", type=str, default="finetune")
+    p.add_argument("--llm_checkpoint", type=str, default="checkpoints/TinyLlama/TinyLlama-1.1B-Chat-v1.0")
+    p.add_argument("--nhyps_key", type=str, default="nhyps_asr")
+    p.add_argument("--dual_hypotheses", action="store_true")
+    p.add_argument("--max_nhyps", type=int, default=None)
+    p.add_argument("--batch_size", type=int, default=32)
+    p.add_argument("--micro_batch_size", type=int, default=1)
+    p.add_argument("--lr", type=float, default=1e-4)
+    p.add_argument("--num_epochs", type=int, default=5)
+    p.add_argument("--weight_decay", type=float, default=0.02)
+    p.add_argument("--d", type=int, default=1, help="number of GPUs")
+    p.add_argument("--lamda", type=float, default=0.5, help="accepted for compatibility (unused in finetune/ger.py too)")
+    p.add_argument("--wp", type=float, default=0.2, help="warm-up proportion of an epoch")
+    p.add_argument("--use_cosine_scheduler", action="store_true")
+    p.add_argument("--min_lr_ratio", type=float, default=0.01)
+    p.add_argument("--log_interval", type=int, default=100)
+    p.add_argument("--save_interval", type=int, default=10000)
+    p.add_argument("--audio_corruption_disabled", action="store_true", help="accepted for compatibility")
+    p.add_argument("--visual_corruption_disabled", action="store_true", help="accepted for compatibility")
+    p.add_argument("--prompts_format", type=str, default="GER")
+    p.add_argument("--apply_chat_template", action="store_true")
+    p.add_argument("--language", type=str, default=None)
+    add_lora_arguments(p)
+    # additions of this build
+    p.add_argument("--tokenizer", choices=("auto", "hf", "byte"), default="auto")
+    p.add_argument("--config_name", type=str, default=None)
+    p.add_argument("--random_init", action="store_true", help="synthetic base weights instead of <llm_checkpoint>/lit_model.pth")
+    p.add_argument("--out_dir", type=str, default=None, help="default ./runs/<exp_name>")
+    p.add_argument("--reference_accumulation", action="store_true", help="quirk Q3: step every batch_size-1 micro-batches")
+    p.add_argument("--seed", type=int, default=1337)
+    args = p.parse_args(argv)
+    if args.apply_chat_template:
+        raise NotImplementedError("--apply_chat_template is outside the hot path")
+    rank, world, dev = init_distributed(args.d)
+    out_dir = Path(args.out_dir or f"./runs/{args.exp_name}")
+    if rank == 0:
+        out_dir.mkdir(parents=True, exist_ok=True)
+        logging.basicConfig(level=logging.INFO, format="%(asctime)s %(message)s",
+                            handlers=[logging.FileHandler(out_dir / "train.log"), logging.StreamHandler()], force=True)
+        logging.info(f"CLI arguments: {args.__dict__}")
+    random.seed(args.seed + rank)
+    torch.manual_seed(args.seed + rank)                    # finetune/ger.py:135
+    from .checkpoint import load_checkpoint
+    from .data import HypothesesDataset, collate
+    from .gpt import GPT
+    from .tokenizer import load_tokenizer
+    cfg = config_from_args(args)
+    tokenizer = load_tokenizer(args.llm_checkpoint, args.tokenizer)
+    max_input_length = 1024                                # finetune/ger.py:417-421
+    tc_path = Path(args.llm_checkpoint) / "tokenizer_config.json"
+    if tc_path.is_file():
+        max_input_length = json.loads(tc_path.read_text()).get("model_max_length") or 1024
+    max_input_length = min(int(max_input_length), cfg.block_size)
+    model = GPT(cfg)
+    if args.random_init:
+        from .synth import synth_state_dict
+        model.load_state_dict(synth_state_dict(cfg, seed=args.seed), strict=True)
+    else:
+        model.load_state_dict(load_checkpoint(Path(args.llm_checkpoint) / "lit_model.pth"), strict=False)   # LoRA tensors keep their init
+    model = model.to(device=dev, dtype=torch.bfloat16)
+    fmt = args.prompts_format if (args.dual_hypotheses or args.prompts_format == "RelPrompt") else "GER"
+
+    def dataset(path, seed):
+        items = []
+        for one in ([path] if isinstance(path, str) else path):
+            with open(one, encoding="utf-8") as f:
+                items += json.load(f)
+        return HypothesesDataset(items, tokenizer, prompts_format=fmt, nhyps_key=args.nhyps_key, max_nhyps=args.max_nhyps,
+                                 max_input_length=max_input_length, language=args.language, seed=seed)
+    train_ds = dataset(args.train_path, args.seed + rank)
+    train = [train_ds[i] for i in range(len(train_ds))]
+    val_batches = None
+    if args.val_path:
+        val_ds = dataset(args.val_path, args.seed)
+        val = [val_ds[i] for i in range(len(val_ds))][rank::world]
+
+        def val_batches():
+            for b in range(0, len(val), args.micro_batch_size):
+                c = collate(val[b:b + args.micro_batch_size])
+                yield {"input_ids": c["input_ids"].to(dev), "labels": c["labels"].to(dev)}
+    tc = TrainConfig(learning_rate=args.lr, weight_decay=args.weight_decay, num_epochs=args.num_epochs, batch_size=args.batch_size,
+                     micro_batch_size=args.micro_batch_size, warmup_frac=args.wp, use_cosine_scheduler=args.use_cosine_scheduler,
+                     min_lr_ratio=args.min_lr_ratio, save_interval=max(args.save_interval // world, 1),
+                     reference_accumulation=args.reference_accumulation)
+    log = logging.info if rank == 0 else (lambda s: None)
+    t0 = time.perf_counter()
+    out = fit(model, train, collate, tc, val_batches=val_batches, out_dir=str(out_dir), rank=rank, world=world, device=dev, log=log)
+    if rank == 0:
+        logging.info(f"Total training time: {time.perf_counter() - t0:.2f}s")
+        logging.info(f"Memory used: {torch.cuda.max_memory_allocated() / 1e9:.02f} GB")
+        logging.info(f"result: {out}")
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+if __name__ == "__main__":
+    main()

@@ -98,20 +98,47 @@ def param_shapes(cfg) -> Dict[str, tuple]:
     return shapes
 
 
+TIE_MUL, TIE_ADD = 7919, 12345     # successor permutation of the tied head: sigma(v) = (TIE_MUL * v + TIE_ADD) mod V
+
+
+def tie_successor(token: int, vocab: int) -> int:
+    """The token a `head_tie` model emits after `token` (the v with sigma(v) == token)."""
+    return ((token - TIE_ADD) * pow(TIE_MUL, -1, vocab)) % vocab
+
+
 def synth_state_dict(cfg, seed: int = 1337, device="cpu", dtype=torch.bfloat16,
-                     norm_jitter: float = 0.0, weight_scale: float = 1.0, head_peak: float = 0.0) -> Dict[str, torch.Tensor]:
+                     norm_jitter: float = 0.0, weight_scale: float = 1.0, head_peak: float = 0.0,
+                     embed_scale: float = 1.0, head_tie: float = 0.0) -> Dict[str, torch.Tensor]:
     """Full state dict with the reference's key names.  `norm_jitter` > 0 perturbs the RMSNorm
     weights away from 1 (used by parity fixtures so the weight multiply is exercised);
     `weight_scale` widens the base/lora_B weights (tiny shapes need it for non-trivial logits);
     `head_peak` > 0 makes `lm_head.adapter_scale` (ger/lora.py:67-71) heavy-tailed, exp(head_peak * E)
     with E ~ Exp(1): i.i.d. Gaussian logits over 32000 tokens put the runner-up within 4 bf16 ulps of
     the arg-max on a quarter of the positions, which makes greedy-id parity untestable; a trained
-    head is peaked, and this reproduces that with the reference's own parameter (0.5: ~2.5 %)."""
+    head is peaked, and this reproduces that with the reference's own parameter (0.5: ~2.5 % by the ulp
+    measure — but a top logit is then scale x (a SMALL dot product), whose bf16 noise is scale x the noise of
+    every dot product, so those margins are only ~1 sigma of what separates two bf16 implementations).
+    `embed_scale` / `head_tie` give margins that ARE robust: the token embedding is scaled (50: it stays visible in
+    the residual stream after 22 random layers) and lm_head[v] += head_tie * wte_unscaled[sigma(v)], so the logit of
+    the successor sigma^-1(last token) stands ~10 logit-std above the rest (>= 20 sigma of bf16 noise, >= 38 ulps on
+    every step at TinyLlama size); every other logit stays a context-dependent random projection."""
     sd: Dict[str, torch.Tensor] = {}
     a = 0.02 * math.sqrt(3.0) * weight_scale
     for name, shape in param_shapes(cfg).items():
         st = stream_id(seed, name)
-        if name.endswith("adapter_bias"):
+        if name == "transformer.wte.weight" and embed_scale != 1.0:
+            t = uniform(shape, a * embed_scale, st, device, dtype)
+        elif name == "lm_head.linear.weight" and head_tie != 0.0:
+            V = shape[0]
+            assert math.gcd(TIE_MUL, V) == 1, "the successor map must be a permutation of the vocabulary"
+            sigma = (TIE_MUL * torch.arange(V, dtype=torch.int64, device=device) + TIE_ADD) % V
+            raw = uniform(shape, a, stream_id(seed, "transformer.wte.weight"), device, torch.float32)   # embedding before embed_scale
+            t = uniform(shape, a, st, device, torch.float32)
+            for r0 in range(0, V, 8192):                  # fp32 elementwise only: bit-identical on CPU and GPU
+                t[r0:r0 + 8192] += head_tie * raw[sigma[r0:r0 + 8192]]
+            t = t.to(dtype)
+            del raw
+        elif name.endswith("adapter_bias"):
             t = torch.zeros(shape, dtype=dtype, device=device)
         elif name.endswith("adapter_scale"):
             t = torch.ones(shape, dtype=dtype, device=device)

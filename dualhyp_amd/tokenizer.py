@@ -12,20 +12,32 @@ from pathlib import Path
 from typing import Iterable, List, Union
 
 
+RELIABILITY_TOKENS = ("<<C>>", "<<M>>", "<<N>>")     # inference/relprompt.py:341
+
+
 class ByteTokenizer:
     bos_token_id, eos_token_id, pad_token_id = 1, 2, 0
     eos_token = "</s>"
     vocab_size = 259
 
+    def __init__(self) -> None:
+        self.special = {self.eos_token: self.eos_token_id}
+
+    def add_reliability_tokens(self, first_id: int) -> None:
+        """<<C>>/<<M>>/<<N>> -> first_id.. (the rows `resize_token_embeddings(3)` appends to wte)."""
+        for i, tok in enumerate(RELIABILITY_TOKENS):
+            self.special[tok] = first_id + i
+
     def encode(self, text: str) -> List[int]:
         ids, rest = [self.bos_token_id], text
-        while rest:                                   # "</s>" in the text is the EOS id, as the HF tokenizer treats it
-            cut = rest.find(self.eos_token)
-            if cut < 0:
+        while rest:                                   # special strings in the text become their ids, as with HF
+            hits = [(rest.find(s), s) for s in self.special if rest.find(s) >= 0]
+            if not hits:
                 ids += [b + 3 for b in rest.encode("utf-8")]
                 break
-            ids += [b + 3 for b in rest[:cut].encode("utf-8")] + [self.eos_token_id]
-            rest = rest[cut + len(self.eos_token):]
+            cut, tok = min(hits)
+            ids += [b + 3 for b in rest[:cut].encode("utf-8")] + [self.special[tok]]
+            rest = rest[cut + len(tok):]
         return ids
 
     def decode(self, ids: Iterable[int]) -> str:
@@ -42,6 +54,12 @@ class _HFTokenizer:
         if tok.pad_token is None:                     # inference/ger.py:200-201
             tok.pad_token = tok.eos_token
         self.eos_token, self.eos_token_id = tok.eos_token, tok.eos_token_id
+
+    def add_reliability_tokens(self, first_id: int) -> None:
+        self.tok.add_special_tokens({"additional_special_tokens": list(RELIABILITY_TOKENS)})
+        got = self.tok.convert_tokens_to_ids(list(RELIABILITY_TOKENS))
+        if got != [first_id, first_id + 1, first_id + 2]:
+            raise ValueError(f"reliability tokens got ids {got}, the decoder's added wte rows are {first_id}..{first_id + 2}")
 
     def encode(self, text: str) -> List[int]:
         return list(self.tok.encode(text))

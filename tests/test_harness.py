@@ -1,0 +1,159 @@
+"""End-to-end harness runs on the GPU (SURVEY.md §8 a17 / f2 / e):
+
+* `python -m dualhyp_amd.inference` — the counterpart of inference/ger.py:127-221 with its flag names — on a 7-item JSON
+  in the merged wire format (data/merge_json.py:5-63): args -> Config.from_name -> checkpoint -> tokenizer -> JSON
+  dataset -> prompt packer -> generate_batch on the HIP model -> predictions JSON + WER fields, checked against
+  `run_inference` fed the ORACLE's ids for the same prompts;
+* `python -m dualhyp_amd.finetune` — finetune/ger.py:371-435 — a short run writing the reference's checkpoint files;
+* data-parallel equivalence without an 8-GPU node: two rank processes on cuda:0 over gloo (the RCCL path itself has not
+  run on hardware yet): fit(world=2, accumulation 2) == fit(world=1, accumulation 4), sharded inference == single process."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYTHONPATH"] = str(ROOT) + os.pathsep + env.get("PYTHONPATH", "")
+    env.update(extra)
+    return env
+
+
+def merged_items(n=7):
+    """Items with every key of the merged schema (data/merge_json.py:5-63; README.md:78-89)."""
+    caps = ["the cat sat on the mat", "we went home early", "it is raining again", "open the window please", "she sells sea shells",
+            "nothing to see here", "turn left at the light"]
+    items = []
+    for i in range(n):
+        c = caps[i % len(caps)]
+        w = c.split()
+        asr = [c, " ".join(w[:-1]), c.replace("the", "a"), " ".join(w[1:]), c + " now"]
+        vsr = [" ".join(reversed(w)), c, c.replace("e", "a"), w[0] + " " + c, " ".join(w[:2])]
+        items.append({"Dataset": "LRS2", "Uid": f"utt{i:03d}", "Caption": c, "Clean_Wav": f"a/{i}.wav", "Noise_Wav": f"n/{i}.wav",
+                      "Noise_Category": {"asr": "babble", "vsr": "occlusion"}, "SNR": -5 + i, "Mouthroi": f"m/{i}.npz",
+                      "Video": f"v/{i}.mp4", "Face_landmark": f"l/{i}.pkl",
+                      "nhyps_asr": {"hyps": asr, "scores": [-0.1 * k for k in range(5)]},
+                      "nhyps_vsr": {"hyps": vsr, "scores": [-0.2 * k for k in range(5)]},
+                      "Audio_Corruption": {"total_len": 32000, "start_fr": 6400, "occ_len": 6400, "snr": -5, "noise_name": "babble"},
+                      "Visual_Corruption": {"total_len": 50, "start_fr": 10, "occ_len": 12},
+                      "WER_1st-hyp": {"asr": 0.0, "vsr": 1.0}})
+    return items
+
+
+NEW = 10
+
+
+def test_inference_harness_end_to_end(tmp_path):
+    from dualhyp_amd import Config
+    from dualhyp_amd.data import HypothesesDataset
+    from dualhyp_amd.inference import run_inference
+    from dualhyp_amd.synth import synth_state_dict
+    from dualhyp_amd.tokenizer import ByteTokenizer
+    from dualhyp_amd.wer import wer_counts, post_normalize
+    from oracle import ger_oracle as O
+    test_json = tmp_path / "test.json"
+    test_json.write_text(json.dumps(merged_items()))
+    ckpt_dir = tmp_path / "checkpoints" / "parity-harness"
+    ckpt_dir.mkdir(parents=True)
+    lora = dict(r=16, alpha=16, dropout=0.05, to_query=True, to_key=True, to_value=True, to_projection=True)
+    cfg = Config.from_name("parity-harness", **lora)
+    sd = synth_state_dict(cfg, seed=31, weight_scale=4.0, embed_scale=64.0, head_tie=1.0)   # robust arg-max margins (synth.py)
+    run_dir = tmp_path / "runs" / "exp"
+    run_dir.mkdir(parents=True)
+    torch.save({"model": sd}, run_dir / "best_model.pth")                      # finetune/ger.py:356-358 format
+    cmd = [sys.executable, "-m", "dualhyp_amd.inference", "--test_path", str(test_json), "--model_path", str(run_dir / "best_model.pth"),
+           "--llm_checkpoint", str(ckpt_dir), "--dual_hypotheses", "--prompts_format", "DualHyp", "--tokenizer", "byte",
+           "--max_new_tokens", str(NEW), "--decode_batch", "4"]
+    out = subprocess.run(cmd, cwd=tmp_path, env=_env(), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    pred_file = run_dir / "predictions" / "best_model.json"                    # inference/ger.py:120-122
+    js = json.loads(pred_file.read_text())
+    assert len(js) == 7 + 2 and set(js[0]) == {"inference", "ground_truth"} and set(js[-2]) == {"wer", "gtms"} and set(js[-1]) == {"post_wer", "post_gtms"}
+    preds = js[:7]
+    assert [p["ground_truth"] for p in preds] == [it["Caption"] for it in merged_items()]
+    c = wer_counts([p["inference"] for p in preds], [p["ground_truth"] for p in preds])
+    assert js[-2]["wer"] == pytest.approx(c["errors"] / c["ref_words"]) and js[-2]["gtms"] == f"{c['exact']}/7"
+    cp = wer_counts([post_normalize(p["inference"]) for p in preds], [post_normalize(p["ground_truth"]) for p in preds])
+    assert js[-1]["post_wer"] == pytest.approx(cp["errors"] / cp["ref_words"])
+    # ---- the same pipeline with the ORACLE as the decoder (CPU, batch 1 as the reference): ids and margins per utterance
+    tok = ByteTokenizer()
+    ds = HypothesesDataset(str(test_json), tok, prompts_format="DualHyp", seed=1337)
+    exs = [ds[i] for i in range(len(ds))]
+    assert all(e["input_no_response"].endswith("### Response:\n") and "### VSR Other-hypotheses:\n" in e["input_no_response"] for e in exs)
+    om = O.OracleGPT(cfg, sd)
+    safe_all, table = [], {}
+    for e in exs:
+        p = e["input_ids_no_response"]
+        ids, trace = O.generate(om, p, p.numel() + NEW, temperature=0.2, top_k=1, eos_id=tok.eos_token_id, mode="argmax", return_logits=True)
+        om.reset_cache()
+        top = torch.topk(trace.float(), 2, dim=-1).values
+        margins = (top[:, 0] - top[:, 1]) / torch.exp2(torch.floor(torch.log2(top[:, 0].abs().clamp_min(1e-30))) - 7)
+        safe_all.append(bool((margins >= 4).all()))
+        table[tuple(p.tolist())] = ids
+    ref = run_inference(lambda ps: [table[tuple(p.tolist())] for p in ps], exs, tok.decode, batch_size=4)
+    n_safe = sum(safe_all)
+    from conftest import record_parity
+    record_parity("harness.inference_vs_oracle", utterances=7, utterances_all_steps_margin_ge4=n_safe,
+                  predictions_equal=sum(a["inference"] == b["inference"] for a, b in zip(preds, ref["predictions"])),
+                  wer_hip=js[-2]["wer"], wer_oracle=ref["WER"])
+    assert n_safe >= 3, "fixture too tie-prone to say anything"
+    for i, ok in enumerate(safe_all):
+        if ok:
+            assert preds[i]["inference"] == ref["predictions"][i]["inference"], f"utterance {i}: HIP harness and oracle disagree on a tie-free decode"
+    if n_safe == 7:
+        assert js[-2]["wer"] == pytest.approx(ref["WER"]) and js[-1]["post_wer"] == pytest.approx(ref["post_ST_wer"])
+
+
+def test_finetune_harness_writes_reference_checkpoints(tmp_path):
+    items = merged_items(6)
+    (tmp_path / "train.json").write_text(json.dumps(items))
+    (tmp_path / "val.json").write_text(json.dumps(items[:2]))
+    ckpt_dir = tmp_path / "checkpoints" / "parity-harness"
+    ckpt_dir.mkdir(parents=True)
+    cmd = [sys.executable, "-m", "dualhyp_amd.finetune", "--train_path", str(tmp_path / "train.json"), "--val_path", str(tmp_path / "val.json"),
+           "--exp_name", "t", "--llm_checkpoint", str(ckpt_dir), "--dual_hypotheses", "--prompts_format", "DualHyp", "--tokenizer", "byte",
+           "--random_init", "--batch_size", "2", "--micro_batch_size", "1", "--lr", "1e-3", "--num_epochs", "1", "--save_interval", "4",
+           "--out_dir", str(tmp_path / "runs" / "t")]
+    out = subprocess.run(cmd, cwd=tmp_path, env=_env(), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    run = tmp_path / "runs" / "t"
+    assert (run / "train.log").is_file() and (run / "lit_model_lora_finetuned.pth").is_file() and (run / "best_model.pth").is_file()
+    ck = torch.load(run / "lit_model_lora_finetuned.pth")
+    assert set(ck) == {"model"} and "transformer.h.0.attn.attn.lora_A" in ck["model"] and "lm_head.linear.weight" in ck["model"]
+    assert float(ck["model"]["transformer.h.0.attn.attn.lora_B"].float().abs().sum()) > 0      # B starts at 0: it was trained
+    assert "optimizer_steps': 3" in (run / "train.log").read_text()
+
+
+def _launch(n, out_path):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29500 + os.getpid() % 500), str(ROOT / "tests" / "dp_worker.py"), "--out", str(out_path)]
+    out = subprocess.run(cmd, cwd=ROOT, env=_env(DUALHYP_DP_REHEARSAL="1"), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    return torch.load(out_path)
+
+
+def test_data_parallel_equivalence(tmp_path):
+    """the same global batch whether 1 rank accumulates 4 micro-batches or 2 ranks accumulate 2 each and
+    all-reduce the flat LoRA-gradient bucket; utterance-sharded inference equals the single-process run."""
+    one = _launch(1, tmp_path / "w1.pt")
+    two = _launch(2, tmp_path / "w2.pt")
+    assert one["world"] == 1 and two["world"] == 2
+    assert one["stats"]["optimizer_steps"] == two["stats"]["optimizer_steps"] == 4
+    worst = 0.0
+    for k, a in one["lora"].items():
+        b = two["lora"][k]
+        worst = max(worst, (a - b).abs().max().item() / max(a.abs().max().item(), 1e-12))
+    from conftest import record_parity
+    record_parity("dp_equivalence.fit_world2_vs_world1", worst_rel_diff_lora_masters=worst, optimizer_steps=4)
+    assert worst <= 2e-3, f"LoRA masters of the 2-rank run differ from the 1-rank run by {worst:.2e} of their max"
+    for k in ("WER", "gtms", "post_ST_wer", "post_gtms", "n"):
+        assert one["inference"][k] == two["inference"][k], k
+    assert one["inference"]["predictions"] == two["inference"]["predictions"] and len(one["inference"]["predictions"]) == 7

@@ -183,7 +183,8 @@ def test_relprompt_decoder(golden, name, tag, dtype):
     over a longer embedding table."""
     t, meta = golden(name)
     cfg = Config(**meta["config"])
-    sd = synth_state_dict(cfg, seed=meta["seed"], norm_jitter=meta["norm_jitter"], weight_scale=meta["weight_scale"])
+    sd = synth_state_dict(cfg, seed=meta["seed"], norm_jitter=meta["norm_jitter"], weight_scale=meta["weight_scale"],
+                          embed_scale=meta["embed_scale"], head_tie=meta["head_tie"])
     V = cfg.padded_vocab_size
     sd["transformer.wte.weight"] = torch.cat([sd["transformer.wte.weight"], t["wte_extra_rows"]])
     sd = {k: v.to(dtype) for k, v in sd.items()}
@@ -252,7 +253,7 @@ def test_full_tinyllama_512(golden):
     """BASELINE config 2's own shape: 22 layers, T = 512, G = 64 (tests/golden/full_tinyllama_512)."""
     t, meta = golden("full_tinyllama_512")
     cfg = Config(**meta["config"])
-    sd = synth_state_dict(cfg, seed=meta["seed"], head_peak=meta["head_peak"])
+    sd = synth_state_dict(cfg, seed=meta["seed"], embed_scale=meta["embed_scale"], head_tie=meta["head_tie"])
     m = O.OracleGPT(cfg, sd)
     T, G = meta["T"], meta["G"]
     got, trace = O.generate(m, t["idx"], T + G, temperature=0.2, top_k=1, mode="argmax", return_logits=True)
@@ -269,7 +270,7 @@ def test_llama3_shape(golden):
     """BASELINE config 5's layer shape (Llama-3-8B: hs 128, 8 groups, I 14336, V 128256), 2 layers."""
     t, meta = golden("llama3_shape")
     cfg = Config(**meta["config"])
-    sd = synth_state_dict(cfg, seed=meta["seed"], head_peak=meta["head_peak"])
+    sd = synth_state_dict(cfg, seed=meta["seed"], embed_scale=meta["embed_scale"], head_tie=meta["head_tie"])
     m = O.OracleGPT(cfg, sd)
     T, G = meta["T"], meta["G"]
     with torch.no_grad():
