@@ -34,6 +34,24 @@ sys.path.insert(0, str(ROOT))
 import torch  # noqa: E402
 
 PROMPT_LEN, NEW_TOKENS, BATCH = 512, 64, 32
+# --config: the headline (BASELINE configs[1]) and the Llama-3-8B side lines (configs[4]: ~1.5k-token 10+10-hypothesis
+# prompts; fp8 = merged LoRA, e4m3 weights with per-channel scales, fp8 MFMA GEMMs)
+WORKLOADS = {
+    "tinyllama-bf16": dict(model="tiny-llama-1.1b-chat", prompt=512, fp8=False, peak=2500.0, in_flight=64, prefill_batches=2,
+                           what="DualHyp inference, TinyLlama-1.1B bf16 + LoRA r16 (q,k,v,proj), batch 32/GPU synthetic 5+5-hyp prompts, "
+                                "512-token prompt -> 64 generated tokens, greedy",
+                           metric="corrected utterances/sec (TinyLlama-1.1B, 5+5 hyps, 512->64 tok)", dtype="bf16",
+                           kernel="gemm_nt256_kernel (prefill GEMMs: qkv+LoRA, proj+LoRA, fc_1/fc_2 SwiGLU, mlp proj)"),
+    "llama3-8b-bf16": dict(model="Llama-3-8B", prompt=1536, fp8=False, peak=2500.0, in_flight=4, prefill_batches=1,
+                           what="DualHyp inference, Llama-3-8B bf16 + LoRA r16, batch 32/GPU synthetic 10+10-hyp prompts, 1536-token prompt -> 64 tokens, greedy",
+                           metric="corrected utterances/sec (Llama-3-8B, 10+10 hyps, 1536->64 tok)", dtype="bf16",
+                           kernel="gemm_nt256_kernel (prefill GEMMs)"),
+    "llama3-8b-fp8": dict(model="Llama-3-8B", prompt=1536, fp8=True, peak=5000.0, in_flight=4, prefill_batches=1,
+                          what="DualHyp inference, Llama-3-8B with merged LoRA, fp8 e4m3 weights (per-channel scales) and per-token fp8 "
+                               "activations, batch 32/GPU synthetic 10+10-hyp prompts, 1536-token prompt -> 64 tokens, greedy",
+                          metric="corrected utterances/sec (Llama-3-8B fp8, 10+10 hyps, 1536->64 tok)", dtype="fp8",
+                          kernel="gemm_fp8_kernel (prefill GEMMs on v_mfma_scale_f32_16x16x128_f8f6f4: qkv, proj, fc_1/fc_2 SwiGLU, mlp proj)"),
+}
 # random-init weights with the head tied to the (scaled) embedding through a fixed permutation (dualhyp_amd.synth):
 # same arithmetic and bytes as plain random init, but the arg-max is separated from the runner-up by tens of bf16 ulps
 # (>= 20 sigma of the noise between two bf16 implementations) on every step, so the greedy ids of the HIP run can be
@@ -44,15 +62,27 @@ MFMA_PEAK_TFLOPS = 2500.0     # bf16 dense, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
 
-def gemm_flops_per_prefill(cfg, n_tok: int, n_seq: int) -> float:
+def gemm_flops_per_prefill(cfg, n_tok: int, n_seq: int, merged_lora: bool = False) -> float:
     """Algorithmic FLOPs of the M>32 GEMM launches of one packed prefill:
     per layer qkv + proj + fc_1 + fc_2 + mlp proj on every token; LoRA rank-16 side products;
     the lm_head runs on the last position only (M = n_seq <= 32: not in this class)."""
     d, I = cfg.n_embd, cfg.intermediate_size
     qkv = (cfg.n_head + 2 * cfg.n_query_groups) * cfg.head_size
     per_tok = 2 * d * (qkv + d + 3 * I)
-    lora = 2 * d * (48 + 16) + 2 * 16 * (qkv + d)
+    lora = (2 * d * (48 + 16) + 2 * 16 * (qkv + d)) if merged_lora is False else 0
     return float(cfg.n_layer * n_tok * (per_tok + lora))
+
+
+def decode_bytes_per_step(cfg, rows: float, mean_ctx: float, weight_bytes: int, merged_lora: bool) -> float:
+    """Algorithmic HBM bytes of one decode step: every dense weight once for all rows + each row's
+    KV prefix (compact GQA cache, bf16)."""
+    d, I = cfg.n_embd, cfg.intermediate_size
+    qkv = (cfg.n_head + 2 * cfg.n_query_groups) * cfg.head_size
+    layer = d * (qkv + d + 3 * I)
+    lora = 0 if merged_lora else cfg.n_layer * (64 * d + 16 * (qkv + d))
+    weights = weight_bytes * (cfg.n_layer * layer + cfg.padded_vocab_size * d) + 2 * lora
+    kv = cfg.n_layer * 2 * cfg.n_query_groups * cfg.head_size * 2
+    return float(weights + rows * kv * mean_ctx)
 
 
 def launch_cmd(n: int, argv: list) -> list:
@@ -86,14 +116,16 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--in-flight", type=int, default=64,
+    ap.add_argument("--config", choices=sorted(WORKLOADS), default="tinyllama-bf16",
+                    help="workload: the headline TinyLlama config (default, the driver's) or a Llama-3-8B side line")
+    ap.add_argument("--in-flight", type=int, default=None,
                     help="batches (steps) decoded together per GPU: each batch of --batch prompts is prefilled on its "
                          "own, then the decode loop runs over all in-flight sequences at once")
     ap.add_argument("--schedule", choices=("merged", "threads"), default="merged",
                     help="merged: one engine, chunked prefill + joint decode (generate_batch); threads: one engine, "
                          "HIP stream and host thread per in-flight batch (dualhyp_amd.pipeline)")
     ap.add_argument("--engines", type=int, default=2, help="--schedule threads: engines (each decodes --in-flight batches jointly)")
-    ap.add_argument("--prefill-batches", type=int, default=2,
+    ap.add_argument("--prefill-batches", type=int, default=None,
                     help="batches per prefill launch (merged schedule): at 2 x 32 x 512 tokens every GEMM of the layer is a whole "
                          "number of 256-tile rounds on 256 CUs (the qkv GEMM is 2.5 rounds at one batch)")
     ap.add_argument("--ragged", action="store_true",
@@ -114,6 +146,12 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.selftest_launch:
         return selftest_launch(a, world)
+    wl = WORKLOADS[a.config]
+    PROMPT_LEN = wl["prompt"]
+    if a.in_flight is None:
+        a.in_flight = wl["in_flight"]
+    if a.prefill_batches is None:
+        a.prefill_batches = wl["prefill_batches"]
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
@@ -141,19 +179,26 @@ def main() -> None:
         for kv in a.tune:
             k, v = kv.split("=")
             _lib.check(_lib.load().dh_set_tuning(int(k), int(v)))
-    cfg = Config.from_name("tiny-llama-1.1b-chat", **{**GER_LORA, "dropout": 0.0})
+    cfg = Config.from_name(wl["model"], **{**GER_LORA, "dropout": 0.0})
+    if "llama-3" in cfg.name.lower():
+        cfg.block_size = 4096                      # inference/ger.py:189-190
     sd = synth_state_dict(cfg, seed=1337, device=dev, **SYNTH_KW)
     model = GPT(cfg).to(device=dev, dtype=torch.bfloat16)
     model.load_state_dict(sd, strict=True)
     del sd
     model.eval()
+    if wl["fp8"]:
+        from dualhyp_amd import quantize_model_fp8
+        quantize_model_fp8(model)                  # merge_lora_weights, then e4m3 rows + channel scales
+        torch.cuda.empty_cache()
     B, G = a.batch, max(1, a.in_flight)
     from dualhyp_amd.generate import generate_batch
     gen_kw = dict(temperature=0.2, top_k=1, eos_id=None)
     # every rank gets its own utterances (strided shard of one synthetic corpus)
     n_warm = max(a.warmup, 1)
     n_batches = a.steps + n_warm
-    corpus = synth_prompts(B * n_batches * world, PROMPT_LEN, cfg.padded_vocab_size, seed=1337, ragged=a.ragged, lo=384, hi=640)
+    corpus = synth_prompts(B * n_batches * world, PROMPT_LEN, cfg.padded_vocab_size, seed=1337, ragged=a.ragged,
+                           lo=PROMPT_LEN * 3 // 4, hi=PROMPT_LEN * 5 // 4)
     mine = [p.to(dev) for p in corpus[rank::world]]
     max_len = max(p.numel() for p in mine)
     batches = [mine[i * B:(i + 1) * B] for i in range(n_batches)]
@@ -220,28 +265,28 @@ def main() -> None:
     result = None
     if rank == 0:
         utt = B * a.steps * world
-        flops = gemm_flops_per_prefill(cfg, sum(p.numel() for p in timed_prompts), B * a.steps)
+        flops = gemm_flops_per_prefill(cfg, sum(p.numel() for p in timed_prompts), B * a.steps, merged_lora=wl["fp8"])
         achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         traffic = None   # HBM-side bytes per launch from the committed PMC passes
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_gemm.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and a.config == "tinyllama-bf16":
             with open(pmc) as fh:
                 traffic = json.load(fh).get("traffic_bytes_per_launch_mean")
         result = {
-            "metric": "corrected utterances/sec (TinyLlama-1.1B, 5+5 hyps, 512->64 tok)",
+            "metric": wl["metric"],
             "value": utt / dt, "unit": "utterances/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "DualHyp inference, TinyLlama-1.1B bf16 + LoRA r16 (q,k,v,proj), batch 32/GPU "
-                                   "synthetic 5+5-hyp prompts, 512-token prompt -> 64 generated tokens, greedy",
-                       "batch_per_gpu": B, "prompt_tokens": "uniform 384..640" if a.ragged else PROMPT_LEN, "new_tokens": NEW_TOKENS,
+            "dtype": wl["dtype"], "data": "synthetic",
+            "config": {"workload": wl["what"],
+                       "batch_per_gpu": B, "prompt_tokens": f"uniform {PROMPT_LEN * 3 // 4}..{PROMPT_LEN * 5 // 4}" if a.ragged else PROMPT_LEN,
+                       "new_tokens": NEW_TOKENS,
                        "parallelism": f"replicas x{world}", "batches_in_flight_per_gpu": G, "schedule": a.schedule,
                        "decode_rows_per_launch": B * min(G, a.steps) if a.schedule == "merged" else B,
                        "prefill_tokens_per_launch": B * PROMPT_LEN * (a.prefill_batches if a.schedule == "merged" else 1),
                        **({"tuning": a.tune} if a.tune else {})},
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt256_kernel (prefill GEMMs: qkv+LoRA, proj+LoRA, fc_1/fc_2 SwiGLU, mlp proj)",
-                         "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic,
+            "roofline": {"bound": "mfma", "kernel": wl["kernel"],
+                         "achieved": achieved, "peak": wl["peak"], "unit": "TFLOP/s",
+                         "frac": achieved / wl["peak"], "traffic": traffic,
                          "traffic_source": "profiles/r01_pmc_gemm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)",
                          "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
                          "prefill_attention_ms_per_step": attn_ms / max(a.steps, 1)},
@@ -251,12 +296,17 @@ def main() -> None:
         # launch plus each sequence's KV prefix; algorithmic bytes per step = 2.078 GB + rows x 22,528 B x S (S ~ 544)
         rows = phase["decode_row_steps"] / phase["decode_steps"]
         step_ms = phase["decode_ms"] / phase["decode_steps"]
-        step_bytes = 2 * (968_884_224 + 65_536_000 + 4_505_600) + rows * 22_528 * (sum(p.numel() for p in timed_prompts) / len(timed_prompts) + NEW_TOKENS / 2)
+        step_bytes = decode_bytes_per_step(cfg, rows, sum(p.numel() for p in timed_prompts) / len(timed_prompts) + NEW_TOKENS / 2,
+                                           1 if wl["fp8"] else 2, merged_lora=wl["fp8"])
         result["phases"] = {"prefill_ms_per_step": phase["prefill_ms"] / a.steps, "decode_ms_per_step": phase["decode_ms"] / a.steps,
                             "decode_loop_ms_per_token": step_ms, "decode_rows_per_launch": rows}
         result["roofline_decode"] = {"bound": "hbm", "achieved": step_bytes / (step_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                      "frac": step_bytes / (step_ms * 1e-3) / 1e9 / 8000.0,
-                                     "bytes_per_decode_step": step_bytes, "kernel": "decode step (157 launches: streaming GEMMs + fused attention)"}
+                                     "bytes_per_decode_step": step_bytes,
+                                     "kernel": "decode step (fp8 weight-streaming GEMMs + split-KV attention)" if wl["fp8"]
+                                     else "decode step (157 launches: streaming GEMMs + fused attention)"}
+    if a.config != "tinyllama-bf16":
+        a.no_overlap_probe = True
     if rank == 0 and world == 1 and a.schedule == "merged" and not a.no_overlap_probe and G > 1:
         # informational: the same engine with ONE batch in flight (prefill, decode 32 rows, next batch)
         reps = [batches[i % n_batches] for i in range(6)]
@@ -284,7 +334,11 @@ def main() -> None:
         result["overlap_probe"] = {"schedule": "threads, 2 engines x %d batches each" % G, "steps": len(reps),
                                    "value": B * len(reps) / (time.perf_counter() - t1), "unit": "utterances/s"}
         pipe.close()
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and a.config != "tinyllama-bf16":
+        # the CPU restatement of an 8B decoder on a 1536-token prompt takes minutes per utterance: outside the
+        # "bounded sample" contract of the default run; parity of this path is asserted in tests/test_hip_fp8.py
+        result["cpu_baseline"] = None
+    elif rank == 0 and world == 1 and not a.no_cpu_baseline:
         # the oracle decodes the FIRST TIMED utterance; its ids and logits are the checker for what the timed run
         # produced for that prompt (parity), its wall time is the CPU baseline
         result["cpu_baseline"], ref = cpu_baseline(cfg, timed_prompts[0].cpu(), NEW_TOKENS)

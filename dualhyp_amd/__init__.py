@@ -9,5 +9,6 @@ from .gpt import GPT, mark_only_lora_as_trainable, lora_filter, merge_lora_weigh
 from .generate import generate, generate_batch  # noqa: F401
 from .utils import chunked_cross_entropy  # noqa: F401
 from .checkpoint import load_checkpoint, save_checkpoint, convert_hf_checkpoint  # noqa: F401
+from .quant import quantize_model_fp8  # noqa: F401
 
 __version__ = "0.1.0"

@@ -19,7 +19,8 @@ F = C.c_float
 
 class LayerWeights(C.Structure):
     _fields_ = [(n, P) for n in ("norm_1", "norm_2", "attn_w", "attn_lora_a", "attn_lora_b", "proj_w",
-                                 "proj_lora_a", "proj_lora_b", "fc_1", "fc_2", "mlp_proj")]
+                                 "proj_lora_a", "proj_lora_b", "fc_1", "fc_2", "mlp_proj",
+                                 "attn_ws", "proj_ws", "fc_1_ws", "fc_2_ws", "mlp_proj_ws")]
 
 
 class ModelDesc(C.Structure):
@@ -27,7 +28,7 @@ class ModelDesc(C.Structure):
                 ("n_embd", C.c_int32), ("intermediate", C.c_int32), ("vocab", C.c_int32), ("block_size", C.c_int32),
                 ("norm_eps", F), ("lora_scale", F), ("wte", P), ("wte_rows", C.c_int32), ("ln_f", P),
                 ("rope_cos", P), ("rope_sin", P), ("lm_head", P), ("adapter_scale", P), ("adapter_bias", P),
-                ("h_layers", C.POINTER(LayerWeights))]
+                ("h_layers", C.POINTER(LayerWeights)), ("lm_head_ws", P)]
 
 
 # name -> (restype, argtypes); must list every function declared in include/dualhyp_hip.h
@@ -56,6 +57,9 @@ SIGNATURES = {
     "dh_attn_decode_work_bytes": (I64, [I, I, I, I]),
     "dh_attn_decode_bf16": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "dh_sample_bf16": (I, [P, I, P, I, P, P, I, F, I, I64, U64, I, P]),
+    "dh_quant_rows_fp8": (I, [P, P, P, I, I, P]),
+    "dh_rmsnorm_quant_fp8": (I, [P, P, P, P, P, I, I, F, P, P]),
+    "dh_linear_fp8": (I, [P, P, P, P, P, I, I, I, I, P, P, P, P, P, P]),
     "dh_engine_create": (I, [C.POINTER(ModelDesc), I, I, I, C.POINTER(P)]),
     "dh_engine_destroy": (None, [P]),
     "dh_engine_device_bytes": (I64, [P]),
@@ -96,7 +100,7 @@ def load() -> C.CDLL:
             raise DualHypHipError(f"libdualhyp_hip.so does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.dh_abi_version() != 1:
+    if lib.dh_abi_version() != 2:
         raise DualHypHipError("libdualhyp_hip.so ABI version mismatch")
     _lib = lib
     return lib

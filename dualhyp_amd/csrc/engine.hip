@@ -43,6 +43,9 @@ struct dh_engine {
     int64_t* dec_ids = nullptr;
     void* dec_work = nullptr;
     float* part32 = nullptr;                            // fp32 partial sums of the decode GEMMs
+    bool fp8 = false;                                   // e4m3 weights + channel scales (csrc/fp8.hip)
+    uint8_t* xq = nullptr;                              // fp8 mode: quantised activations [max_tokens, max(d, I)]
+    float* xscale = nullptr;                            // fp8 mode: their per-token scales [max_tokens]
     int32_t* h_stage = nullptr;                         // pinned staging for the metadata
     size_t cache_layer_elems = 0;
     int64_t dev_bytes = 0;
@@ -186,6 +189,78 @@ int run_layers(dh_engine* e, const int64_t* ids, int n_tok, int n_seq, int max_q
     return 0;
 }
 
+// fp8 serving: the same layer sequence with every dense product on the fp8 MFMA (csrc/fp8.hip).  Activations are
+// quantised per token right where they are produced (the norm kernels) or by a pass over the attention / SwiGLU
+// output; LoRA is merged into the weights before quantisation, so there is no rank-16 side product.  Prefill and
+// decode run the same sequence; dh_linear_fp8 picks the weight-streaming kernel for <= 32 rows.
+int run_layers_fp8(dh_engine* e, const int64_t* ids, int n_tok, int n_seq, int max_q_len, bool decode,
+                   const uint8_t* tail_flags, hipStream_t s) {
+    const uint8_t* rt = e->rsqrt_vec > 0 ? tail_flags : nullptr;
+    e->phase_decode = decode;
+    const dh_model_desc& D = e->d;
+    const int d = D.n_embd, I = D.intermediate, hs = D.head_size, H = D.n_head, G = D.n_groups;
+    int32_t* seq_slot = e->seq_meta + e->slot_base;
+    int32_t* q_start = e->seq_meta + e->max_batch;
+    int32_t* q_len = e->seq_meta + 2 * e->max_batch;
+    int32_t* kv_pos0 = e->seq_meta + 3 * e->max_batch;   // decode: kv_len
+    int rc;
+    // the weight pointers of dh_layer_weights address e4m3 bytes in this mode
+    auto lin = [&](const bf16_t* w, const float* ws, bf16_t* y, int N, int K, int epi, const bf16_t* w2, const float* w2s,
+                   const bf16_t* res) {
+        return dh_linear_fp8(e->xq, e->xscale, reinterpret_cast<const uint8_t*>(w), ws, y, n_tok, N, K, epi,
+                             reinterpret_cast<const uint8_t*>(w2), w2s, nullptr, nullptr, res, s);
+    };
+    if ((rc = dh_embed_bf16(ids, D.wte, e->x, n_tok, d, D.wte_rows, s))) return rc;
+    for (int l = 0; l < D.n_layer; ++l) {
+        const dh_layer_weights& W = e->layers[l];
+        bf16_t* kc = e->kc + (size_t)l * e->cache_layer_elems;
+        bf16_t* vtc = e->vtc + (size_t)l * e->cache_layer_elems;
+        if ((rc = dh_rmsnorm_quant_fp8(e->x, W.norm_1, nullptr, e->xq, e->xscale, n_tok, d, D.norm_eps, rt, s))) return rc;
+        {
+            TimeScope t(e, decode ? 1 : 0, s);
+            if ((rc = lin(W.attn_w, W.attn_ws, e->qkv, e->qkv_dim, d, DH_EPI_PLAIN, nullptr, nullptr, nullptr))) return rc;
+        }
+        if ((rc = dh_qkv_rope_cache_bf16(e->qkv, D.rope_cos, D.rope_sin, e->tok_slot, e->tok_pos, e->qrot, kc, vtc, nullptr,
+                                         nullptr, n_tok, H, G, hs, e->s_max, s))) return rc;
+        if (decode) {
+            TimeScope t(e, 3, s);
+            if ((rc = dh_attn_decode_bf16(e->qrot, kc, vtc, seq_slot, kv_pos0, e->att, e->dec_work, n_seq, H, G, hs,
+                                          e->s_max, s))) return rc;
+        } else {
+            TimeScope t(e, 2, s);
+            if ((rc = dh_attn_prefill_bf16(e->qrot, kc, vtc, seq_slot, q_start, q_len, kv_pos0, e->att, nullptr, n_seq,
+                                           max_q_len, H, G, hs, e->s_max, s))) return rc;
+        }
+        if ((rc = dh_quant_rows_fp8(e->att, e->xq, e->xscale, n_tok, d, s))) return rc;
+        {
+            TimeScope t(e, decode ? 1 : 0, s);
+            if ((rc = lin(W.proj_w, W.proj_ws, e->x, d, d, DH_EPI_PLAIN, nullptr, nullptr, e->x))) return rc;
+        }
+        if ((rc = dh_rmsnorm_quant_fp8(e->x, W.norm_2, nullptr, e->xq, e->xscale, n_tok, d, D.norm_eps, rt, s))) return rc;
+        {
+            TimeScope t(e, decode ? 1 : 0, s);
+            if ((rc = lin(W.fc_1, W.fc_1_ws, e->act, I, d, DH_EPI_SWIGLU, W.fc_2, W.fc_2_ws, nullptr))) return rc;
+        }
+        if ((rc = dh_quant_rows_fp8(e->act, e->xq, e->xscale, n_tok, I, s))) return rc;
+        {
+            TimeScope t(e, decode ? 1 : 0, s);
+            if ((rc = lin(W.mlp_proj, W.mlp_proj_ws, e->x, d, I, DH_EPI_PLAIN, nullptr, nullptr, e->x))) return rc;
+        }
+    }
+    return 0;
+}
+
+// ln_f + lm_head of `rows` rows of `xrows` in fp8 mode; the bf16 ln_f output lands in e->xn as in the bf16 path
+int head_fp8(dh_engine* e, const bf16_t* xrows, int rows, bf16_t* logits, const uint8_t* rt, hipStream_t s) {
+    const dh_model_desc& D = e->d;
+    int rc;
+    if ((rc = dh_rmsnorm_quant_fp8(xrows, D.ln_f, e->xn, e->xq, e->xscale, rows, D.n_embd, D.norm_eps,
+                                   e->rsqrt_vec > 0 ? rt : nullptr, s))) return rc;
+    TimeScope t(e, e->phase_decode ? 1 : 0, s);
+    return dh_linear_fp8(e->xq, e->xscale, reinterpret_cast<const uint8_t*>(D.lm_head), D.lm_head_ws, logits, rows, D.vocab,
+                         D.n_embd, DH_EPI_ADAPTER, nullptr, nullptr, D.adapter_scale, D.adapter_bias, nullptr, s);
+}
+
 // K-slices of 8 (or 16 for long K) k-steps: the row-parallel streaming kernel (gemm_skinny.hip)
 int pick_ksplit(int tiles, int nks) {
     (void)tiles;
@@ -294,6 +369,14 @@ int engine_init(dh_engine* e, const dh_model_desc* desc, int max_batch, int s_ma
     const int d = desc->n_embd, hs = desc->head_size, G = desc->n_groups, H = desc->n_head;
     e->kv_dim = G * hs;
     e->qkv_dim = (H + 2 * G) * hs;
+    e->fp8 = e->layers[0].attn_ws != nullptr;
+    if (e->fp8) {
+        for (const auto& L : e->layers)
+            DH_CHECK(L.attn_ws && L.proj_ws && L.fc_1_ws && L.fc_2_ws && L.mlp_proj_ws && !L.attn_lora_a && !L.proj_lora_a,
+                     "dh_engine_create: fp8 mode needs every channel-scale pointer and merged LoRA (no lora_a/lora_b)");
+        DH_CHECK(desc->lm_head_ws != nullptr, "dh_engine_create: fp8 mode needs lm_head_ws");
+        DH_CHECK(d % 128 == 0 && desc->intermediate % 128 == 0, "dh_engine_create: fp8 mode needs n_embd and intermediate %% 128 == 0");
+    }
     e->cache_layer_elems = (size_t)max_batch * G * s_max * hs;
     const size_t T = max_tokens;
     int rc = 0;
@@ -315,6 +398,10 @@ int engine_init(dh_engine* e, const dh_model_desc* desc, int max_batch, int s_ma
     rc |= dmalloc(e, &e->step_dev, 1);
     rc |= dmalloc(e, &e->dec_ids, (size_t)max_batch);
     rc |= dmalloc(e, &e->part32, (size_t)16 * (max_batch < 32 ? 32 : (max_batch < MAX_DECODE_ROWS ? max_batch : MAX_DECODE_ROWS)) * (e->qkv_dim + 48));
+    if (e->fp8) {
+        rc |= dmalloc(e, &e->xq, T * (size_t)(desc->intermediate > d ? desc->intermediate : d));
+        rc |= dmalloc(e, &e->xscale, T);
+    }
     rc |= dmalloc(e, &e->row_tail, T);
     rc |= dmalloc(e, &e->last_tail, (size_t)max_batch);
     rc |= dmalloc(e, &e->ones, (size_t)max_batch);
@@ -343,7 +430,7 @@ extern "C" void dh_engine_destroy(dh_engine* e) {
     for (auto& g : e->graphs) hipGraphExecDestroy(g.exec);
     void* ptrs[] = {e->kc, e->vtc, e->x, e->xn, e->qkv, e->qrot, e->att, e->xa, e->act, e->xlast, e->logits,
                     e->tok_slot, e->tok_pos, e->seq_meta, e->last_row, e->step_dev, e->dec_ids, e->dec_work,
-                    e->row_tail, e->last_tail, e->ones, e->part32};
+                    e->row_tail, e->last_tail, e->ones, e->part32, e->xq, e->xscale};
     for (void* p : ptrs)
         if (p) hipFree(p);
     if (e->h_stage) hipHostFree(e->h_stage);
@@ -435,6 +522,18 @@ extern "C" int dh_engine_forward_at(dh_engine* e, const int64_t* ids, const int3
     int rc;
     // one token per sequence == a decode step (what generate()'s loop issues): same kernels as dh_engine_decode
     e->decode_tiled = max_q == 1 && g_decode_tiled_rows > 0 && n_seq >= g_decode_tiled_rows;
+    if (e->fp8) {
+        if ((rc = run_layers_fp8(e, ids, n_tok, n_seq, max_q, max_q == 1, e->row_tail, s))) return rc;
+        e->last_ntok = n_tok;
+        if (logits_all && (rc = head_fp8(e, e->x, n_tok, logits_all, e->row_tail, s))) return rc;
+        if (logits_last) {
+            hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(n_seq, 4)), dim3(256), 0, s, e->x, e->last_row, e->xlast, n_seq,
+                               e->d.n_embd);
+            DH_LAUNCH_CHECK();
+            if ((rc = head_fp8(e, e->xlast, n_seq, logits_last, e->last_tail, s))) return rc;
+        }
+        return 0;
+    }
     const bool fast = max_q == 1 && n_seq <= MAX_DECODE_ROWS && e->d.n_embd % 16 == 0 && !e->decode_tiled;
     if (fast) {
         if ((rc = run_layers_decode(e, ids, n_seq, e->row_tail, s))) return rc;
@@ -472,7 +571,10 @@ int decode_step(dh_engine* e, int64_t* tokens, int tok_ld, int32_t* length, int3
     DH_LAUNCH_CHECK();
     int rc;
     e->decode_tiled = g_decode_tiled_rows > 0 && n_seq >= g_decode_tiled_rows;
-    if (n_seq <= MAX_DECODE_ROWS && !e->decode_tiled) {
+    if (e->fp8) {
+        if ((rc = run_layers_fp8(e, e->dec_ids, n_seq, n_seq, 1, true, e->ones, s))) return rc;
+        if ((rc = head_fp8(e, e->x, n_seq, e->logits, e->ones, s))) return rc;
+    } else if (n_seq <= MAX_DECODE_ROWS && !e->decode_tiled) {
         if ((rc = run_layers_decode(e, e->dec_ids, n_seq, e->ones, s))) return rc;
         if ((rc = head_normed(e, n_seq, e->logits, s))) return rc;
     } else {

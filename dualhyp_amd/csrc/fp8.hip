@@ -1,0 +1,489 @@
+// fp8 (OCP e4m3fn) serving path — BASELINE config 5: merged-LoRA weights quantised per output channel, activations
+// quantised per token at run time, products on the block-scaled fp8 MFMA of gfx950 (v_mfma_scale_f32_16x16x128_f8f6f4
+// with unit block scales: twice the bf16 rate per clock), per-channel x per-token scales applied to the fp32
+// accumulator in the epilogue:
+//     y[m,n] = bf16( (sum_k xq[m,k] * wq[n,k]) * (x_scale[m] * w_scale[n]) )
+//     q = fp8_rne(v * inv),  inv = 448 / amax (IEEE fp32 division),  scale = amax * fp32(1/448),  amax = max|row| (>= 1e-12)
+// The reference has no fp8 code (ger/lora.py:152-157,349-365,707-711 are the merge this path starts from); the
+// arithmetic is restated on the CPU in oracle/ger_oracle.py (quantize_rows_fp8 / linear_fp8) with torch's e4m3fn type.
+//
+//   quant_rows_fp8_kernel       bf16 rows -> e4m3 rows + one fp32 scale per row (one wave per row, two passes)
+//   rmsnorm_quant_fp8_kernel    RMSNorm (ger/rmsnorm.py:17-21, bf16 rounding points) with the quantisation fused
+//   gemm_fp8_kernel             M > 32: 128 x 128 x 128 tiles, both operands through LDS (global_load_lds 16 B, rows
+//                               of 128 B with the source-side XOR swizzle of gemm.hip), 4 waves x (4 x 4) MFMA tiles
+//   gemm_fp8_skinny_kernel      M <= 32 (decode): W streamed HBM -> VGPR once, K dealt over the 8 waves of a block
+// MFMA operand map (checked with integer data, tests/test_hip_fp8.py): lane l holds the 32 consecutive k
+// [32 (l >> 4), 32 (l >> 4) + 32) of row (A) / column (B) l & 15 — one MX block per lane, hence one scale per lane.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+namespace {
+
+constexpr float FP8_MAX = 448.0f;
+constexpr float INV_FP8_MAX = 1.0f / 448.0f;   // the fp32 nearest to 1/448: a constant on both sides, not a division
+constexpr int UNIT_SCALE = 0x7F7F7F7F;   // four E8M0 bytes of 2^0
+
+__device__ __forceinline__ uint32_t pack4_fp8(float a, float b, float c, float d) {
+    int v = 0;
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);   // OCP e4m3fn on gfx950, round to nearest even
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+    return (uint32_t)v;
+}
+
+__device__ __forceinline__ f32x4 mfma_fp8(const i32x8& a, const i32x8& b, const f32x4& c) {
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0 /* A e4m3 */, 0 /* B e4m3 */, 0, UNIT_SCALE, 0, UNIT_SCALE);
+}
+
+// ------------------------------------------------------------------------------ row quantisation
+__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __restrict__ x, uint8_t* __restrict__ q,
+                                                             float* __restrict__ scale, int rows, int K) {
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int nchunk = K >> 3;
+    const uint4* xr = reinterpret_cast<const uint4*>(x + (size_t)row * K);
+    float amax = 0.f;
+    for (int c = lane; c < nchunk; c += 64) {
+        const uint4 u = xr[c];
+        const bf16_t* p = reinterpret_cast<const bf16_t*>(&u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(bf2f(p[j])));
+    }
+    amax = fmaxf(wave_max(amax), 1e-12f);
+    const float inv = __fdiv_rn(FP8_MAX, amax);         // correctly rounded, as the oracle's tensor / tensor division
+    if (lane == 0) scale[row] = amax * INV_FP8_MAX;
+    uint2* qr = reinterpret_cast<uint2*>(q + (size_t)row * K);
+    for (int c = lane; c < nchunk; c += 64) {
+        const uint4 u = xr[c];                         // second pass: an L2 hit
+        const bf16_t* p = reinterpret_cast<const bf16_t*>(&u);
+        qr[c] = make_uint2(pack4_fp8(bf2f(p[0]) * inv, bf2f(p[1]) * inv, bf2f(p[2]) * inv, bf2f(p[3]) * inv),
+                           pack4_fp8(bf2f(p[4]) * inv, bf2f(p[5]) * inv, bf2f(p[6]) * inv, bf2f(p[7]) * inv));
+    }
+}
+
+// RMSNorm as elementwise.hip's rmsnorm_kernel (same rounding points, same Q11 flag) whose bf16 output row is
+// quantised before it leaves the registers; xn_out (nullable) still receives the bf16 row.
+template <int MAXC>
+__global__ __launch_bounds__(256) void rmsnorm_quant_fp8_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                                bf16_t* __restrict__ xn_out, uint8_t* __restrict__ q,
+                                                                float* __restrict__ scale, int rows, int d, float eps,
+                                                                const uint8_t* __restrict__ row_tail) {
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int nchunk = d >> 3;
+    const uint4* xr = reinterpret_cast<const uint4*>(x + (size_t)row * d);
+    float v[MAXC][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nchunk) {
+            const uint4 u = xr[c];
+            const bf16_t* p = reinterpret_cast<const bf16_t*>(&u);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[i][j] = bf2f(p[j]);
+                ss += rbf(v[i][j] * v[i][j]);
+            }
+        }
+    }
+    ss = wave_sum(ss);
+    const float ms = rbf(ss / (float)d);
+    const float t = rbf(ms + eps);
+    const bool tail = row_tail != nullptr && row_tail[row] != 0;
+    const float r = tail ? rbf(1.0f / rbf(sqrtf(t))) : rbf(1.0f / sqrtf(t));
+    const uint4* wr = reinterpret_cast<const uint4*>(w);
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nchunk) {
+            const uint4 wu = wr[c];
+            const bf16_t* wp = reinterpret_cast<const bf16_t*>(&wu);
+            uint4 o;
+            bf16_t* op = reinterpret_cast<bf16_t*>(&o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                op[j] = f2bf(bf2f(wp[j]) * rbf(v[i][j] * r));
+                v[i][j] = bf2f(op[j]);
+                amax = fmaxf(amax, fabsf(v[i][j]));
+            }
+            if (xn_out) reinterpret_cast<uint4*>(xn_out + (size_t)row * d)[c] = o;
+        }
+    }
+    amax = fmaxf(wave_max(amax), 1e-12f);
+    const float inv = __fdiv_rn(FP8_MAX, amax);
+    if (lane == 0) scale[row] = amax * INV_FP8_MAX;
+    uint2* qr = reinterpret_cast<uint2*>(q + (size_t)row * d);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = lane + i * 64;
+        if (c < nchunk)
+            qr[c] = make_uint2(pack4_fp8(v[i][0] * inv, v[i][1] * inv, v[i][2] * inv, v[i][3] * inv),
+                               pack4_fp8(v[i][4] * inv, v[i][5] * inv, v[i][6] * inv, v[i][7] * inv));
+    }
+}
+
+// ------------------------------------------------------------------------------ GEMM argument block
+struct Fp8Args {
+    const uint8_t* x;      // [M, K] e4m3
+    const uint8_t* w;      // [N, K] e4m3
+    const uint8_t* w2;     // SWIGLU: fc_2
+    bf16_t* y;             // [M, N]
+    const float* xs;       // [M] activation scales
+    const float* ws;       // [N] channel scales of w
+    const float* ws2;      // [N] channel scales of w2
+    const bf16_t* vec_a;   // ADAPTER scale [N]
+    const bf16_t* vec_b;   // ADAPTER bias [N]
+    const bf16_t* resid;   // [M, N] or null
+    int M, N, K;
+    int nb_n, nb_m;
+};
+
+constexpr int BT = 128;                 // block tile edge
+constexpr int BKB = 128;                // bytes (= fp8 elements) of K per stage and row
+constexpr int TILE_BYTES = BT * BKB;    // 16 KiB
+
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+
+// finish one accumulator value: scale, round, epilogue (the bf16 rounding points of the bf16 path)
+template <int EPI>
+__device__ __forceinline__ float fp8_finish(float acc, float sc, const Fp8Args& a, int n) {
+    float o = rbf(acc * sc);
+    if (EPI == DH_EPI_ADAPTER) o = rbf(bf2f(a.vec_a[n]) * rbf(o + bf2f(a.vec_b[n])));
+    return o;
+}
+
+// ------------------------------------------------------------------------------ tiled kernel (M > 32)
+// Same skeleton as gemm.hip's gemm_nt_kernel: C^T tiles (A operand = W rows, B operand = x rows), XCD-aware
+// tile order, NST LDS stages with counted vmcnt.  A stage is one MFMA k-step: 128 k = 128 bytes per row.
+template <int EPI, bool RESID, int NST>
+__global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(Fp8Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // NST x (W tile 16 KiB + x tile 16 KiB)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wm = wave & 1;
+    const int nwg = a.nb_n * a.nb_m;
+    int tile;
+    {
+        const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tm = tile / a.nb_n, tn = tile % a.nb_n;
+    const int m0 = tm * BT;
+    const int n0 = (EPI == DH_EPI_SWIGLU) ? tn * 64 : tn * BT;
+
+    const uint8_t* srcA[4];
+    const uint8_t* srcB[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int R = wave * 4 + j;               // 1-KiB row group: LDS rows R*8 .. R*8+7
+        const int row = R * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ swz(row);  // logical 16-B chunk held by this LDS slot
+        {
+            const uint8_t* base = a.w;
+            int n;
+            if (EPI == DH_EPI_SWIGLU) {
+                const int half = (row >> 5) & 1;  // 32-row halves of a wave's 64 rows: 0 = fc_1, 1 = fc_2
+                n = n0 + (row >> 6) * 32 + (row & 31);
+                base = half ? a.w2 : a.w;
+            } else {
+                n = n0 + row;
+            }
+            n = n < a.N ? n : a.N - 1;
+            srcA[j] = base + (size_t)n * a.K + chunk * 16;
+        }
+        {
+            int m = m0 + row;
+            m = m < a.M ? m : a.M - 1;
+            srcB[j] = a.x + (size_t)m * a.K + chunk * 16;
+        }
+    }
+    auto stage = [&](int buf, int kt) {
+        char* sA = smem + buf * 2 * TILE_BYTES;
+        char* sB = sA + TILE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int R = wave * 4 + j;
+            glds16(srcA[j] + (size_t)kt * BKB, sA + R * 1024);
+            glds16(srcB[j] + (size_t)kt * BKB, sB + R * 1024);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, kg = lane >> 4;
+    const int offA = (wn * 64 + frow) * 128, offB = (wm * 64 + frow) * 128;
+    const int c0 = ((2 * kg) ^ swz(frow)) << 4, c1 = ((2 * kg + 1) ^ swz(frow)) << 4;
+    const int nk = a.K / BKB;
+    auto frag = [&](const char* base) __attribute__((always_inline)) -> i32x8 {
+        const uint4 lo = *reinterpret_cast<const uint4*>(base + c0);
+        const uint4 hi = *reinterpret_cast<const uint4*>(base + c1);
+        return i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+    };
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const char* sA = smem + buf * 2 * TILE_BYTES;
+        const char* sB = sA + TILE_BYTES;
+        i32x8 fa[4], fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa[i] = frag(sA + offA + i * 2048);
+            fb[i] = frag(sB + offB + i * 2048);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma_fp8(fa[i], fb[j], acc[i][j]);
+    };
+    if constexpr (NST == 2) {
+        stage(0, 0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+            compute(cur);
+            __syncthreads();
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < NST - 1; ++p)
+            if (p < nk) stage(p, p);
+        if (2 < nk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 3 < nk) stage((kt + 3) % NST, kt + 3);
+            compute(kt % NST);
+            if (kt + 3 < nk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    // accumulator element r of tile (i,j): n = nt + 4*kg + r ; m = mt + frow
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wm * 64 + j * 16 + frow;
+        if (m >= a.M) continue;
+        const float xs = a.xs[m];
+        if (EPI == DH_EPI_SWIGLU) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int n = n0 + wn * 32 + i * 16 + 4 * kg;
+                if (n >= a.N) continue;
+                const float4 s1 = *reinterpret_cast<const float4*>(a.ws + n), s2 = *reinterpret_cast<const float4*>(a.ws2 + n);
+                const float* s1p = reinterpret_cast<const float*>(&s1);
+                const float* s2p = reinterpret_cast<const float*>(&s2);
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float g = rbf(acc[i][j][e] * (xs * s1p[e]));
+                    const float u = rbf(acc[i + 2][j][e] * (xs * s2p[e]));
+                    o[e] = rbf(g / (1.0f + expf(-g))) * u;
+                }
+                *reinterpret_cast<uint2*>(a.y + (size_t)m * a.N + n) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int n = n0 + wn * 64 + i * 16 + 4 * kg;
+                if (n >= a.N) continue;
+                const float4 s1 = *reinterpret_cast<const float4*>(a.ws + n);
+                const float* s1p = reinterpret_cast<const float*>(&s1);
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = fp8_finish<EPI>(acc[i][j][e], xs * s1p[e], a, n + e);
+                if (RESID) {
+                    const uint2 rr = *reinterpret_cast<const uint2*>(a.resid + (size_t)m * a.N + n);
+                    const bf16_t* rp = reinterpret_cast<const bf16_t*>(&rr);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = bf2f(rp[e]) + o[e];
+                }
+                *reinterpret_cast<uint2*>(a.y + (size_t)m * a.N + n) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ streaming kernel (M <= 32)
+// As gemm_skinny.hip's gemm_skinny_kernel: one block = 16 W rows (SWIGLU: of fc_1 and fc_2), K dealt round-robin in
+// 128-wide k-steps over the 8 waves, W global -> VGPR (non-temporal, each byte is needed once), the per-wave fp32
+// partials meet in LDS and thread t finishes output (n = t & 15, m = t >> 4).
+constexpr int ROWS = 16, NW = 8;
+
+template <int EPI, bool RESID>
+__global__ __launch_bounds__(512, 2) void gemm_fp8_skinny_kernel(Fp8Args a) {
+    constexpr bool SW = EPI == DH_EPI_SWIGLU;
+    constexpr int CH = SW ? 2 : 4;                        // k-steps (32 B per lane and operand) loaded ahead per wave
+    __shared__ __attribute__((aligned(16))) float part[NW][32][ROWS];
+    __shared__ __attribute__((aligned(16))) float part2[SW ? NW : 1][32][ROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * ROWS;
+    const int lrow = lane & 15, kg = lane >> 4;
+    int n = n0 + lrow;
+    n = n < a.N ? n : a.N - 1;
+    const uint8_t* wrow = a.w + (size_t)n * a.K + kg * 32;
+    const uint8_t* wrow2 = SW ? a.w2 + (size_t)n * a.K + kg * 32 : nullptr;
+    int m_lo = lrow, m_hi = 16 + lrow;
+    m_lo = m_lo < a.M ? m_lo : a.M - 1;
+    m_hi = m_hi < a.M ? m_hi : a.M - 1;
+    const uint8_t* xlo = a.x + (size_t)m_lo * a.K + kg * 32;
+    const uint8_t* xhi = a.x + (size_t)m_hi * a.K + kg * 32;
+    auto ldw = [](const uint8_t* p) __attribute__((always_inline)) -> i32x8 {
+        const i32x4 lo = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(p));
+        const i32x4 hi = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(p + 16));
+        return i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
+    auto ldx = [](const uint8_t* p) __attribute__((always_inline)) -> i32x8 {
+        const uint4 lo = *reinterpret_cast<const uint4*>(p);
+        const uint4 hi = *reinterpret_cast<const uint4*>(p + 16);
+        return i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+    };
+    f32x4 acc_lo = {0.f, 0.f, 0.f, 0.f}, acc_hi = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc2_lo = {0.f, 0.f, 0.f, 0.f}, acc2_hi = {0.f, 0.f, 0.f, 0.f};
+    const int nks = a.K / 128;
+    for (int ks0 = wave; ks0 < nks; ks0 += NW * CH) {
+        i32x8 wf[CH], wf2[CH], xl[CH], xh[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int ks = ks0 + c * NW;
+            if (ks < nks) {
+                wf[c] = ldw(wrow + (size_t)ks * 128);
+                if (SW) wf2[c] = ldw(wrow2 + (size_t)ks * 128);
+                xl[c] = ldx(xlo + (size_t)ks * 128);
+                xh[c] = ldx(xhi + (size_t)ks * 128);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int ks = ks0 + c * NW;
+            if (ks < nks) {
+                acc_lo = mfma_fp8(wf[c], xl[c], acc_lo);
+                acc_hi = mfma_fp8(wf[c], xh[c], acc_hi);
+                if (SW) {
+                    acc2_lo = mfma_fp8(wf2[c], xl[c], acc2_lo);
+                    acc2_hi = mfma_fp8(wf2[c], xh[c], acc2_hi);
+                }
+            }
+        }
+    }
+    // C layout: col (m) = lane & 15, rows (n) = 4*(lane>>4) + reg
+    *reinterpret_cast<f32x4*>(&part[wave][lrow][kg * 4]) = acc_lo;
+    *reinterpret_cast<f32x4*>(&part[wave][16 + lrow][kg * 4]) = acc_hi;
+    if (SW) {
+        *reinterpret_cast<f32x4*>(&part2[wave][lrow][kg * 4]) = acc2_lo;
+        *reinterpret_cast<f32x4*>(&part2[wave][16 + lrow][kg * 4]) = acc2_hi;
+    }
+    __syncthreads();
+    const int tn = tid & 15, tm = tid >> 4, nn = n0 + tn;
+    if (tm >= a.M || nn >= a.N) return;
+    const float* p = &part[0][0][0] + tm * ROWS + tn;
+    const float xs = a.xs[tm];
+    float o;
+    if (SW) {
+        float g = 0.f, u = 0.f;
+        const float* p2 = &part2[0][0][0] + tm * ROWS + tn;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            g += p[w * 32 * ROWS];
+            u += p2[w * 32 * ROWS];
+        }
+        g = rbf(g * (xs * a.ws[nn]));
+        u = rbf(u * (xs * a.ws2[nn]));
+        o = rbf(g / (1.0f + expf(-g))) * u;
+    } else {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s += p[w * 32 * ROWS];
+        o = fp8_finish<EPI>(s, xs * a.ws[nn], a, nn);
+        if (RESID) o = bf2f(a.resid[(size_t)tm * a.N + nn]) + o;
+    }
+    a.y[(size_t)tm * a.N + nn] = f2bf(o);
+}
+
+template <int EPI, bool RESID, int NST>
+int launch_tiled_n(const Fp8Args& a, hipStream_t s) {
+    constexpr int lds = NST * 2 * TILE_BYTES;
+    DH_MAX_LDS_ONCE((gemm_fp8_kernel<EPI, RESID, NST>), lds);
+    hipLaunchKernelGGL((gemm_fp8_kernel<EPI, RESID, NST>), dim3(a.nb_n * a.nb_m), dim3(256), lds, s, a);
+    DH_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int EPI>
+int launch_tiled(const Fp8Args& a, hipStream_t s) {
+    // as gemm.hip: grids smaller than the chip walk K alone -> 4 stages, one block per CU; else 2 stages, two blocks
+    if (a.nb_n * a.nb_m < 384) return a.resid ? launch_tiled_n<EPI, true, 4>(a, s) : launch_tiled_n<EPI, false, 4>(a, s);
+    return a.resid ? launch_tiled_n<EPI, true, 2>(a, s) : launch_tiled_n<EPI, false, 2>(a, s);
+}
+
+template <int EPI>
+int launch_skinny(const Fp8Args& a, hipStream_t s) {
+    dim3 grid(cdiv(a.N, ROWS)), block(512);
+    if (a.resid) hipLaunchKernelGGL((gemm_fp8_skinny_kernel<EPI, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gemm_fp8_skinny_kernel<EPI, false>), grid, block, 0, s, a);
+    DH_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int dh_quant_rows_fp8(const dh_bf16* x, uint8_t* q, float* scale, int rows, int K, void* stream) {
+    DH_CHECK(x && q && scale && rows >= 0 && K > 0 && K % 8 == 0, "dh_quant_rows_fp8: bad argument (K %% 8 must be 0)");
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, q, scale, rows, K);
+    DH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dh_rmsnorm_quant_fp8(const dh_bf16* x, const dh_bf16* w, dh_bf16* xn_out, uint8_t* q, float* scale, int rows,
+                                    int d, float eps, const uint8_t* row_tail, void* stream) {
+    DH_CHECK(x && w && q && scale, "dh_rmsnorm_quant_fp8: null argument");
+    DH_CHECK(rows >= 0 && d > 0 && d % 8 == 0 && d <= 8192, "dh_rmsnorm_quant_fp8: unsupported d=%d (need d %% 8 == 0, d <= 8192)", d);
+    if (rows == 0) return 0;
+    dim3 grid(cdiv(rows, 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH(MAXC) hipLaunchKernelGGL((rmsnorm_quant_fp8_kernel<MAXC>), grid, block, 0, s, x, w, xn_out, q, scale, rows, d, eps, row_tail)
+    if (d <= 512) { LAUNCH(1); }
+    else if (d <= 2048) { LAUNCH(4); }
+    else if (d <= 4096) { LAUNCH(8); }
+    else { LAUNCH(16); }
+#undef LAUNCH
+    DH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dh_linear_fp8(const uint8_t* xq, const float* x_scale, const uint8_t* wq, const float* w_scale, dh_bf16* y,
+                             int M, int N, int K, int epilogue, const uint8_t* w2q, const float* w2_scale,
+                             const dh_bf16* vec_a, const dh_bf16* vec_b, const dh_bf16* resid, void* stream) {
+    DH_CHECK(xq && x_scale && wq && w_scale && y, "dh_linear_fp8: null operand");
+    DH_CHECK(M >= 0 && N > 0 && K > 0 && K % 128 == 0 && N % 4 == 0, "dh_linear_fp8: bad shape M=%d N=%d K=%d (K %% 128, N %% 4 must be 0)", M, N, K);
+    DH_CHECK(epilogue == DH_EPI_PLAIN || epilogue == DH_EPI_SWIGLU || epilogue == DH_EPI_ADAPTER,
+             "dh_linear_fp8: epilogue %d unsupported (LoRA is merged before quantisation)", epilogue);
+    DH_CHECK(epilogue != DH_EPI_SWIGLU || (w2q && w2_scale && !resid), "dh_linear_fp8: SWIGLU needs w2/w2_scale and takes no residual");
+    DH_CHECK(epilogue != DH_EPI_ADAPTER || (vec_a && vec_b), "dh_linear_fp8: ADAPTER needs scale/bias vectors");
+    if (M == 0) return 0;
+    Fp8Args a{xq, wq, w2q, y, x_scale, w_scale, w2_scale, vec_a, vec_b, resid, M, N, K, 0, 0};
+    hipStream_t s = (hipStream_t)stream;
+    if (M <= 32) {
+        switch (epilogue) {
+            case DH_EPI_PLAIN: return launch_skinny<DH_EPI_PLAIN>(a, s);
+            case DH_EPI_SWIGLU: return launch_skinny<DH_EPI_SWIGLU>(a, s);
+            default: return launch_skinny<DH_EPI_ADAPTER>(a, s);
+        }
+    }
+    a.nb_m = cdiv(M, BT);
+    a.nb_n = epilogue == DH_EPI_SWIGLU ? cdiv(N, 64) : cdiv(N, BT);
+    switch (epilogue) {
+        case DH_EPI_PLAIN: return launch_tiled<DH_EPI_PLAIN>(a, s);
+        case DH_EPI_SWIGLU: return launch_tiled<DH_EPI_SWIGLU>(a, s);
+        default: return launch_tiled<DH_EPI_ADAPTER>(a, s);
+    }
+}

@@ -294,12 +294,32 @@ class _Engine:
             self.keep.append(t)
             return t.data_ptr()
 
+        fp8 = bool(getattr(model, "fp8", False))
+
+        def wptr(lin) -> Optional[int]:
+            """bf16 weight, or the e4m3 bytes of a quantised layer (dualhyp_amd.quant)"""
+            if not fp8:
+                return ptr(lin.weight.data)
+            t = lin.weight_fp8
+            assert t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()
+            self.keep.append(t)
+            return t.data_ptr()
+
+        def sptr(lin) -> Optional[int]:
+            if not fp8:
+                return None
+            t = lin.weight_scale
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+            self.keep.append(t)
+            return t.data_ptr()
+
         scale = 0.0
         for l, blk in enumerate(model.transformer.h):
             w = layers[l]
             w.norm_1, w.norm_2 = ptr(blk.norm_1.weight.data), ptr(blk.norm_2.weight.data)
             qkv, proj = blk.attn.attn, blk.attn.proj
-            w.attn_w, w.proj_w = ptr(qkv.linear.weight.data), ptr(proj.linear.weight.data)
+            w.attn_w, w.proj_w = wptr(qkv.linear), wptr(proj.linear)
+            w.attn_ws, w.proj_ws = sptr(qkv.linear), sptr(proj.linear)
             if qkv.lora_active and any(qkv.enable_lora):
                 A, B = qkv.padded_lora()
                 w.attn_lora_a, w.attn_lora_b = ptr(A), ptr(B)
@@ -308,17 +328,18 @@ class _Engine:
                 A, B = proj.padded_lora()
                 w.proj_lora_a, w.proj_lora_b = ptr(A), ptr(B)
                 scale = proj.scaling
-            w.fc_1, w.fc_2 = ptr(blk.mlp.fc_1.linear.weight.data), ptr(blk.mlp.fc_2.linear.weight.data)
-            w.mlp_proj = ptr(blk.mlp.proj.linear.weight.data)
+            w.fc_1, w.fc_2 = wptr(blk.mlp.fc_1.linear), wptr(blk.mlp.fc_2.linear)
+            w.mlp_proj = wptr(blk.mlp.proj.linear)
+            w.fc_1_ws, w.fc_2_ws, w.mlp_proj_ws = sptr(blk.mlp.fc_1.linear), sptr(blk.mlp.fc_2.linear), sptr(blk.mlp.proj.linear)
         cos, sin = model.rope_cache
         desc = _lib.ModelDesc(
             n_layer=cfg.n_layer, n_head=cfg.n_head, n_groups=cfg.n_query_groups, head_size=cfg.head_size,
-            n_embd=cfg.n_embd, intermediate=cfg.intermediate_size, vocab=model.lm_head.linear.weight.size(0),
+            n_embd=cfg.n_embd, intermediate=cfg.intermediate_size, vocab=model.lm_head.adapter_scale.size(0),
             block_size=cfg.block_size, norm_eps=cfg.norm_eps, lora_scale=scale,
             wte=ptr(model.transformer.wte.weight.data), wte_rows=model.transformer.wte.weight.size(0),
             ln_f=ptr(model.transformer.ln_f.weight.data), rope_cos=ptr(cos), rope_sin=ptr(sin),
-            lm_head=ptr(model.lm_head.linear.weight.data), adapter_scale=ptr(model.lm_head.adapter_scale.data),
-            adapter_bias=ptr(model.lm_head.adapter_bias.data), h_layers=layers)
+            lm_head=wptr(model.lm_head.linear), adapter_scale=ptr(model.lm_head.adapter_scale.data),
+            adapter_bias=ptr(model.lm_head.adapter_bias.data), h_layers=layers, lm_head_ws=sptr(model.lm_head.linear))
         self.max_batch, self.s_max, self.max_tokens = max_batch, s_max, max_tokens
         self.vocab = desc.vocab
         self.device = model.transformer.wte.weight.device
@@ -514,7 +535,7 @@ class GPT(nn.Module):
             # incremental decoding whatever the grad mode — the reference allows it outside no_grad() — and
             # runs through the engine below, which returns logits without a graph.
             from .train import forward_train, lora_parameters
-            if any(p.requires_grad for p in lora_parameters(self)):
+            if not getattr(self, "fp8", False) and any(p.requires_grad for p in lora_parameters(self)):
                 return forward_train(self, idx, lm_head_chunk_size)
         if use_kv_cache:
             pos = input_pos.tolist() if input_pos.numel() <= 2 else [int(input_pos[0]), int(input_pos[-1])]

@@ -157,6 +157,47 @@ def sample(logits: torch.Tensor, tokens: torch.Tensor, length: torch.Tensor, don
                                      int(seed) & ((1 << 64) - 1), int(step), _stream()))
 
 
+def quant_rows_fp8(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(uint8 e4m3 [rows, K], fp32 scale [rows]) of bf16 rows; dh_quant_rows_fp8."""
+    x = _dev(x, name="x")
+    K = x.size(-1)
+    rows = x.numel() // K
+    q = torch.empty((rows, K), dtype=torch.uint8, device=x.device)
+    s = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(_lib.load().dh_quant_rows_fp8(_p(x), _p(q), _p(s), rows, K, _stream()))
+    return q, s
+
+
+def rmsnorm_quant_fp8(x: torch.Tensor, w: torch.Tensor, eps: float, row_tail: Optional[torch.Tensor] = None):
+    """(bf16 RMSNorm rows, their e4m3 bytes, fp32 scales); dh_rmsnorm_quant_fp8."""
+    k = _Keep()
+    x = _dev(x, name="x")
+    d = x.size(-1)
+    rows = x.numel() // d
+    xn = torch.empty_like(x)
+    q = torch.empty((rows, d), dtype=torch.uint8, device=x.device)
+    s = torch.empty(rows, dtype=torch.float32, device=x.device)
+    check(_lib.load().dh_rmsnorm_quant_fp8(_p(x), k(w, name="weight"), _p(xn), _p(q), _p(s), rows, d, float(eps),
+                                           k(row_tail, torch.uint8, "row_tail"), _stream()))
+    return xn, q, s
+
+
+def linear_fp8(xq: torch.Tensor, x_scale: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor, *, epilogue: int = EPI_PLAIN,
+               w2q: Optional[torch.Tensor] = None, w2_scale: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
+               bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bf16 [M, N] = epilogue((xq . wq^T) * x_scale[m] * w_scale[n]) on the fp8 MFMA; dh_linear_fp8."""
+    k = _Keep()
+    M, K = xq.shape
+    N = wq.size(0)
+    assert wq.size(1) == K and xq.dtype == torch.uint8 and wq.dtype == torch.uint8
+    y = torch.empty((M, N), dtype=torch.bfloat16, device=xq.device)
+    check(_lib.load().dh_linear_fp8(k(xq, torch.uint8, "xq"), k(x_scale, torch.float32, "x_scale"), k(wq, torch.uint8, "wq"),
+                                    k(w_scale, torch.float32, "w_scale"), _p(y), M, N, K, epilogue, k(w2q, torch.uint8, "w2q"),
+                                    k(w2_scale, torch.float32, "w2_scale"), k(scale, name="scale"), k(bias, name="bias"),
+                                    k(resid, name="resid"), _stream()))
+    return y
+
+
 def im2col3(x: torch.Tensor, ld: int, relu: bool = False) -> torch.Tensor:
     """[B*T, ld] im2col matrix of a k=3, pad=1 convolution over x [B,T,C] with a ones column at 3C; dh_im2col3_bf16."""
     x = _dev(x, name="x")

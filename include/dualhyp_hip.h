@@ -26,7 +26,7 @@ extern "C" {
 
 typedef uint16_t dh_bf16;
 
-#define DH_ABI_VERSION 1
+#define DH_ABI_VERSION 2
 
 int dh_abi_version(void);
 /* Kernel-variant selector for benchmarking (key 0: decode partial-sum GEMM, 0 = K split over the
@@ -224,6 +224,24 @@ int dh_sample_bf16(const dh_bf16* logits, int vocab, int64_t* tokens, int tok_ld
                    int32_t* done, int n_seq, float temperature, int top_k, int64_t eos_id,
                    uint64_t seed, int step, void* stream);
 
+/* ------------------------------------------------------------------ fp8 serving path (csrc/fp8.hip)
+ * W8A8 with OCP e4m3fn: q = fp8_rne(v * (448 / amax)), scale = amax / 448 per row (amax >= 1e-12, fp32 arithmetic);
+ * weights are quantised per output channel ahead of time (dualhyp_amd.quant, after merge_lora_weights), activations
+ * per token by the two kernels below.  The CPU restatement is oracle/ger_oracle.py: quantize_rows_fp8 / linear_fp8. */
+
+/* q[r,:] e4m3 [rows, K], scale[r] fp32 from bf16 rows.  K %% 8 == 0. */
+int dh_quant_rows_fp8(const dh_bf16* x, uint8_t* q, float* scale, int rows, int K, void* stream);
+/* dh_rmsnorm_bf16 (no residual) whose bf16 output row is quantised in registers; xn_out (nullable) receives the bf16 row. */
+int dh_rmsnorm_quant_fp8(const dh_bf16* x, const dh_bf16* w, dh_bf16* xn_out, uint8_t* q, float* scale, int rows, int d,
+                         float eps, const uint8_t* row_tail, void* stream);
+/* y[M,N] bf16 = epilogue( bf16( (xq . wq^T in fp32) * (x_scale[m] * w_scale[n]) ) ) on the block-scaled fp8 MFMA
+ * (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales).  K %% 128 == 0, N %% 4 == 0.  Epilogues: DH_EPI_PLAIN
+ * (+ resid), DH_EPI_SWIGLU (w2q / w2_scale = fc_2), DH_EPI_ADAPTER (vec_a scale, vec_b bias).  M <= 32 streams the
+ * weights once (decode), larger M runs 128 x 128 x 128 tiles. */
+int dh_linear_fp8(const uint8_t* xq, const float* x_scale, const uint8_t* wq, const float* w_scale, dh_bf16* y, int M, int N,
+                  int K, int epilogue, const uint8_t* w2q, const float* w2_scale, const dh_bf16* vec_a, const dh_bf16* vec_b,
+                  const dh_bf16* resid, void* stream);
+
 /* ------------------------------------------------------------------ decoder engine
  * Native runtime that owns the kernel sequence of ger/lora.py:504-549 for a whole batch:
  * embed -> n_layer x [norm_1, qkv(+LoRA), rope+cache, attention, proj(+LoRA)+residual,
@@ -243,6 +261,15 @@ typedef struct dh_layer_weights {
     const dh_bf16* fc_1;        /* [I, d]                                      */
     const dh_bf16* fc_2;        /* [I, d]                                      */
     const dh_bf16* mlp_proj;    /* [d, I]                                      */
+    /* fp8 serving (BASELINE config 5; merged-LoRA path of ger/lora.py:152-157,349-365,707-711): when attn_ws is
+     * non-NULL every *_ws must be, the five weight pointers above then address OCP e4m3 bytes [N, K] produced by
+     * dualhyp_amd.quant (LoRA already merged: attn_lora_* / proj_lora_* NULL) and these are the fp32 scales per
+     * output channel, [N] each. */
+    const float* attn_ws;
+    const float* proj_ws;
+    const float* fc_1_ws;
+    const float* fc_2_ws;
+    const float* mlp_proj_ws;
 } dh_layer_weights;
 
 typedef struct dh_model_desc {
@@ -258,6 +285,7 @@ typedef struct dh_model_desc {
     const dh_bf16* adapter_scale; /* [vocab] */
     const dh_bf16* adapter_bias;  /* [vocab] */
     const dh_layer_weights* h_layers; /* host array [n_layer] (copied) */
+    const float* lm_head_ws;    /* fp8 serving: [vocab] channel scales, lm_head then addresses e4m3 bytes; else NULL */
 } dh_model_desc;
 
 typedef struct dh_engine dh_engine;

@@ -282,3 +282,26 @@ def test_llama3_shape(golden):
     margins = t["generate_margins_ulps"]
     safe = G if (margins >= 2).all() else int((margins < 2).nonzero()[0])
     assert torch.equal(got[: T + safe], t["generate_ids"][: T + safe])
+
+
+def test_fp8_restatement_is_consistent():
+    """The fp8 serving scheme (not in the reference): the oracle's quantiser and the product's (dualhyp_amd.quant)
+    produce the same bytes and scales; dequantised weights are within e4m3's half-ulp of the originals; the quantised
+    tied-head decoder keeps the bf16 decoder's greedy ids."""
+    from dualhyp_amd.quant import quantize_rows_fp8, dequantize_rows_fp8
+    from dualhyp_amd.synth import synth_prompts
+    w = uniform((96, 512), 0.05, stream_id(5, "w8"))
+    q, s = O.quantize_rows_fp8(w)
+    q2, s2 = quantize_rows_fp8(w)
+    assert torch.equal(q.view(torch.uint8), q2) and torch.equal(s.view(-1), s2)
+    back = dequantize_rows_fp8(q2, s2)
+    assert ((back - w.float()).abs() <= w.float().abs().amax(-1, keepdim=True) / 448.0 * 16 * 1.001).all()   # half an e4m3 step at the top binade
+    assert (back - w.float()).abs().max() / w.float().abs().max() < 2 ** -4
+    cfg = Config.from_name("parity-hs128", r=16, alpha=16, dropout=0.0, to_query=True, to_key=True, to_value=True, to_projection=True)
+    sd = synth_state_dict(cfg, seed=3, norm_jitter=0.25, weight_scale=4.0, embed_scale=64.0, head_tie=1.0)
+    sq = O.quantize_state_dict_fp8(sd, cfg)
+    assert "transformer.h.0.attn.attn.lora_A" not in sq and sq["lm_head.linear.weight"].dtype == torch.float8_e4m3fn
+    idx = synth_prompts(1, 30, cfg.padded_vocab_size, seed=9)[0]
+    a = O.generate(O.OracleGPT(cfg, sd), idx, 38, temperature=0.2, top_k=1, mode="argmax")
+    b = O.generate(O.OracleGPT(cfg, sq), idx, 38, temperature=0.2, top_k=1, mode="argmax")
+    assert torch.equal(a, b)
