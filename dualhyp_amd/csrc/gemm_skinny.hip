@@ -261,14 +261,17 @@ __global__ __launch_bounds__(512, 2) void gemm_skinny_partial_kernel(const bf16_
     y32[((size_t)blockIdx.y * m_total + tm) * N + nn] = s;   // [ksplit][m_total][N], this launch's rows at y32
 }
 
-// Row-parallel variant: the 8 waves of a block own 16 W rows EACH (128 rows per block) and all
+// Row-parallel variant: the 8 waves of a block own 16*CT W rows EACH (128*CT rows per block) and all
 // work on the SAME K-slice, so the x slice [32*NG x 32*KPS] is staged once per block in LDS (x is
 // 2/3 of the load instructions when every wave fetches its own fragments) and no cross-wave
-// reduction is needed: each wave stores its fp32 tile straight from the accumulators.  NG 32-row
+// reduction is needed: each wave stores its fp32 tiles straight from the accumulators.  NG 32-row
 // groups of x (several batches decoded in one launch) reuse the W fragments held in registers; when
 // NG groups do not fit in LDS they pass through it NGL at a time (W is still streamed once).
-//   grid (ceil(N/128), ksplit, ceil(M / (32*NG))), K-slice = KPS k-steps of 32.
-template <int KPS, int NG, int NGL>
+// CT (column tiles per wave): with one tile every MFMA needs its own ds_read_b128 of x and from ~128 rows on the
+// LDS port, not the weight stream, bounds the kernel (rocprof at 640 rows: 275-316 TFLOP/s); with CT tiles one x
+// fragment feeds CT MFMAs.  The summation order is untouched: same K-slices, same chain inside a slice.
+//   grid (ceil(N/(128*CT)), ksplit, ceil(M / (32*NG))), K-slice = KPS k-steps of 32.
+template <int KPS, int NG, int NGL, int CT>
 __global__ __launch_bounds__(512, NG == 1 ? 2 : 1) void gemm_skinny_rows_kernel(const bf16_t* __restrict__ x,
                                                                               const bf16_t* __restrict__ w,
                                                                               const bf16_t* __restrict__ w_ext,
@@ -279,19 +282,21 @@ __global__ __launch_bounds__(512, NG == 1 ? 2 : 1) void gemm_skinny_rows_kernel(
     extern __shared__ __attribute__((aligned(16))) char sx[];   // [NGL*32][XS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, kg = lane >> 4;
-    const int n0 = blockIdx.x * 128 + wave * 16;
+    const int n0 = blockIdx.x * (128 * CT) + wave * (16 * CT);
     const int m0 = blockIdx.z * (NG * 32);
     const int nks = K / 32;
     const int ks_begin = blockIdx.y * KPS;
     const int ks_cnt = min(KPS, nks - ks_begin);          // >= 1 by construction of the grid
-    int n = n0 + lrow;
-    n = n < N ? n : N - 1;
-    const bf16_t* wrow = (n < n_main ? w + (size_t)n * K : w_ext + (size_t)(n - n_main) * K) + ks_begin * 32 + kg * 8;
-    bf16x8 wf[KPS];
+    bf16x8 wf[CT][KPS];
 #pragma unroll
-    for (int c = 0; c < KPS; ++c)
-        if (c < ks_cnt) wf[c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wrow + c * 32));
-    const int nn = n0 + kg * 4;
+    for (int ct = 0; ct < CT; ++ct) {
+        int n = n0 + ct * 16 + lrow;
+        n = n < N ? n : N - 1;
+        const bf16_t* wrow = (n < n_main ? w + (size_t)n * K : w_ext + (size_t)(n - n_main) * K) + ks_begin * 32 + kg * 8;
+#pragma unroll
+        for (int c = 0; c < KPS; ++c)
+            if (c < ks_cnt) wf[ct][c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wrow + c * 32));
+    }
 #pragma unroll
     for (int r0 = 0; r0 < NG; r0 += NGL) {
         const int mr = m0 + r0 * 32;                       // first row of this LDS round
@@ -314,35 +319,46 @@ __global__ __launch_bounds__(512, NG == 1 ? 2 : 1) void gemm_skinny_rows_kernel(
         for (int g = 0; g < NGL; ++g) {
             const int mg = mr + g * 32;
             if (mg >= M) break;
-            f32x4 acc_lo = {0.f, 0.f, 0.f, 0.f}, acc_hi = {0.f, 0.f, 0.f, 0.f};
+            f32x4 acc_lo[CT], acc_hi[CT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) acc_lo[ct] = acc_hi[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < KPS; ++c) {
                 if (c < ks_cnt) {
                     const bf16x8 xl = *reinterpret_cast<const bf16x8*>(sx + (g * 32 + lrow) * XS + c * 64 + kg * 16);
                     const bf16x8 xh = *reinterpret_cast<const bf16x8*>(sx + (g * 32 + 16 + lrow) * XS + c * 64 + kg * 16);
-                    acc_lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c], xl, acc_lo, 0, 0, 0);
-                    acc_hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c], xh, acc_hi, 0, 0, 0);
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        acc_lo[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][c], xl, acc_lo[ct], 0, 0, 0);
+                        acc_hi[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][c], xh, acc_hi[ct], 0, 0, 0);
+                    }
                 }
             }
-            if (nn < N) {
-                float* out = y32 + (size_t)blockIdx.y * M * N + nn;
-                if (mg + lrow < M) *reinterpret_cast<f32x4*>(out + (size_t)(mg + lrow) * N) = acc_lo;
-                if (mg + 16 + lrow < M) *reinterpret_cast<f32x4*>(out + (size_t)(mg + 16 + lrow) * N) = acc_hi;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int nn = n0 + ct * 16 + kg * 4;
+                if (nn < N) {
+                    float* out = y32 + (size_t)blockIdx.y * M * N + nn;
+                    if (mg + lrow < M) *reinterpret_cast<f32x4*>(out + (size_t)(mg + lrow) * N) = acc_lo[ct];
+                    if (mg + 16 + lrow < M) *reinterpret_cast<f32x4*>(out + (size_t)(mg + 16 + lrow) * N) = acc_hi[ct];
+                }
             }
         }
     }
 }
 
-template <int KPS, int NG>
+int g_rows_ct = 0;   // 0: by row count; else forced column tiles per wave (dh_set_tuning key 11: 1, 2 or 4)
+
+template <int KPS, int NG, int CT>
 int launch_rows(const bf16_t* x, const bf16_t* w, const bf16_t* w_ext, float* y32, int M, int n_main, int N, int K,
                 int ksplit, hipStream_t s) {
     constexpr int XS = KPS * 64 + 16;
     constexpr int NGL = NG * 32 * XS <= 144 * 1024 ? NG : NG / 2;   // groups resident in LDS at once
     constexpr int lds = NGL * 32 * XS;
     static_assert(lds <= 160 * 1024, "x slice does not fit in LDS");
-    if (lds > 48 * 1024) DH_MAX_LDS_ONCE((gemm_skinny_rows_kernel<KPS, NG, NGL>), lds);
-    dim3 grid((N + 127) / 128, ksplit, cdiv(M, NG * 32)), block(512);
-    hipLaunchKernelGGL((gemm_skinny_rows_kernel<KPS, NG, NGL>), grid, block, lds, s, x, w, w_ext, y32, M, n_main, N, K);
+    if (lds > 48 * 1024) DH_MAX_LDS_ONCE((gemm_skinny_rows_kernel<KPS, NG, NGL, CT>), lds);
+    dim3 grid(cdiv(N, 128 * CT), ksplit, cdiv(M, NG * 32)), block(512);
+    hipLaunchKernelGGL((gemm_skinny_rows_kernel<KPS, NG, NGL, CT>), grid, block, lds, s, x, w, w_ext, y32, M, n_main, N, K);
     DH_LAUNCH_CHECK();
     return 0;
 }
@@ -350,10 +366,17 @@ int launch_rows(const bf16_t* x, const bf16_t* w, const bf16_t* w_ext, float* y3
 template <int KPS>
 int launch_rows_ng(const bf16_t* x, const bf16_t* w, const bf16_t* w_ext, float* y32, int M, int n_main, int N, int K,
                    int ksplit, hipStream_t s) {
-    if (M <= 32) return launch_rows<KPS, 1>(x, w, w_ext, y32, M, n_main, N, K, ksplit, s);
-    if (M <= 64) return launch_rows<KPS, 2>(x, w, w_ext, y32, M, n_main, N, K, ksplit, s);
-    if (M <= 128) return launch_rows<KPS, 4>(x, w, w_ext, y32, M, n_main, N, K, ksplit, s);
-    return launch_rows<KPS, 8>(x, w, w_ext, y32, M, n_main, N, K, ksplit, s);
+    if (M <= 32) return launch_rows<KPS, 1, 1>(x, w, w_ext, y32, M, n_main, N, K, ksplit, s);
+    if (M <= 64) return launch_rows<KPS, 2, 1>(x, w, w_ext, y32, M, n_main, N, K, ksplit, s);
+    if (M <= 128) return launch_rows<KPS, 4, 1>(x, w, w_ext, y32, M, n_main, N, K, ksplit, s);
+    // CT > 1 (several column tiles per wave, one x fragment read feeding CT MFMAs; same bits) was measured at 640 rows:
+    // no change (6.44 vs 6.45 ms per decode step) — the kernel is bound by the partial-sum stores and the x staging, not
+    // by the fragment reads — so one tile per wave stays the default; dh_set_tuning(11, ct) selects the others
+    constexpr int CTMAX = KPS == 8 ? 4 : 2;               // W fragments: CT * KPS * 4 VGPRs
+    const int ct = g_rows_ct ? g_rows_ct : 1;
+    if (ct >= 4 && CTMAX >= 4) return launch_rows<KPS, 8, CTMAX>(x, w, w_ext, y32, M, n_main, N, K, ksplit, s);
+    if (ct >= 2) return launch_rows<KPS, 8, 2>(x, w, w_ext, y32, M, n_main, N, K, ksplit, s);
+    return launch_rows<KPS, 8, 1>(x, w, w_ext, y32, M, n_main, N, K, ksplit, s);
 }
 
 int g_skinny_variant = 1;   // 0: K split over the waves of a block, 1: row-parallel with LDS-staged x
@@ -428,6 +451,7 @@ extern "C" int dh_set_tuning(int key, int value) {
     if (key == 8) { extern int g_dt_stages; g_dt_stages = value; return 0; }
     if (key == 9) { extern int g_gemm128_stages; g_gemm128_stages = value; return 0; }
     if (key == 10 && value >= 0) { extern int g_decode_tiled_rows; g_decode_tiled_rows = value; return 0; }
+    if (key == 11 && value >= 0) { g_rows_ct = value; return 0; }
     dh_set_error("dh_set_tuning: unknown key %d", key);
     return 1;
 }
