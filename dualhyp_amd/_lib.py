@@ -8,7 +8,9 @@ import ctypes as C
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "lib" / "libdualhyp_hip.so"
+import os as _os
+# DUALHYP_HIP_LIB: another build of the same ABI (kernel A/B comparisons inside one gpurun call)
+LIB_PATH = Path(_os.environ["DUALHYP_HIP_LIB"]) if _os.environ.get("DUALHYP_HIP_LIB") else _HERE / "lib" / "libdualhyp_hip.so"
 
 P = C.c_void_p
 I = C.c_int

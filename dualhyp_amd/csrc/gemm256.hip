@@ -280,10 +280,45 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     constexpr int NT = EPI == DH_EPI_SWIGLU ? 4 : 8;              // output tiles of 16 columns per wave
     const int nw0 = n0 + wn * (NT * 16);
+    // Everything the epilogue reads from memory is requested in BATCHES before it is used: the LoRA B rows of the
+    // wave's 8 column tiles once, and per row strip the 8 x·A^T fragments and the 8 residual words.  Issued one by one
+    // inside the tile loop (load -> MFMA -> store, y may alias resid) they cost one L2 round trip each: ~14 us per
+    // 256 x 256 tile of the proj GEMM, a quarter of its fixed per-tile cost.
+    bf16x8 lbv[EPI == DH_EPI_LORA ? NT : 1];
+    if (EPI == DH_EPI_LORA) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            int nn = nw0 + i * 16 + frow;
+            nn = nn < a.N ? nn : a.N - 1;
+            lbv[i] = kg < 2 ? *reinterpret_cast<const bf16x8*>(a.lora_b + (size_t)nn * 16 + kg * 8) : zero8;   // rank 16 zero-padded to K = 32
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int m = m0 + wm * 64 + j * 16 + frow;
         const bool m_ok = m < a.M;
+        bf16x8 xfv[EPI == DH_EPI_LORA ? NT : 1];
+        if (EPI == DH_EPI_LORA) {
+            const int mm = m_ok ? m : a.M - 1;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int nt = nw0 + i * 16;
+                const int seg = (nt >= a.split0) + (nt >= a.split1);
+                xfv[i] = kg < 2 ? *reinterpret_cast<const bf16x8*>(a.xa + (size_t)mm * a.xa_ld + seg * 16 + kg * 8) : zero8;
+            }
+        }
+        // residual in the layout of the paired 16-byte stores below (8 consecutive columns per lane): the add is done
+        // after the permlane swap, on values that are already bf16-exact, so the rounding is that of bf16(resid + y)
+        uint4 rrv[RESID ? NT / 2 : 1];
+        if (RESID) {
+#pragma unroll
+            for (int ip = 0; ip < NT / 2; ++ip) {
+                const int nb = nw0 + ip * 32;
+                rrv[ip] = (m_ok && nb + 32 <= a.N)
+                              ? *reinterpret_cast<const uint4*>(a.resid + (size_t)m * a.N + nb + (kg & 1) * 16 + (kg >> 1) * 8)
+                              : make_uint4(0, 0, 0, 0);
+            }
+        }
         // packed bf16 x4 of output tile i for this lane (all lanes run it: the swap below is wave-wide)
         auto tile_value = [&](int i) __attribute__((always_inline)) -> uint2 {
             const int nt = nw0 + i * 16, n = nt + kg * 4;
@@ -300,17 +335,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = rbf(acc[i][j][e]);
                 if (EPI == DH_EPI_LORA) {
-                    const int seg = (nt >= a.split0) + (nt >= a.split1);
-                    int nn = nt + frow;
-                    nn = nn < a.N ? nn : a.N - 1;
-                    const int mm = m_ok ? m : a.M - 1;
-                    bf16x8 lb = zero8, xf = zero8;          // rank 16 zero-padded to the MFMA's K = 32
-                    if (kg < 2) {
-                        lb = *reinterpret_cast<const bf16x8*>(a.lora_b + (size_t)nn * 16 + kg * 8);
-                        xf = *reinterpret_cast<const bf16x8*>(a.xa + (size_t)mm * a.xa_ld + seg * 16 + kg * 8);
-                    }
                     f32x4 lacc = {0.f, 0.f, 0.f, 0.f};
-                    lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lb, xf, lacc, 0, 0, 0);
+                    lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lbv[EPI == DH_EPI_LORA ? i : 0], xfv[EPI == DH_EPI_LORA ? i : 0], lacc, 0, 0, 0);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = rbf(o[e] + rbf(rbf(lacc[e]) * a.lora_scale));
                 }
@@ -322,12 +348,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = rbf(bf2f(sp[e]) * rbf(o[e] + bf2f(bp[e])));
                 }
-                if (RESID && ok) {
-                    const uint2 rr = *reinterpret_cast<const uint2*>(a.resid + (size_t)m * a.N + n);
-                    const bf16_t* rp = reinterpret_cast<const bf16_t*>(&rr);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = bf2f(rp[e]) + o[e];
-                }
             }
             return make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
         };
@@ -338,13 +358,28 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
             if (nb + 32 <= a.N) {
                 const auto rx = __builtin_amdgcn_permlane16_swap(ta.x, tb.x, false, false);
                 const auto ry = __builtin_amdgcn_permlane16_swap(ta.y, tb.y, false, false);
-                if (m_ok)
-                    *reinterpret_cast<uint4*>(a.y + (size_t)m * a.N + nb + (kg & 1) * 16 + (kg >> 1) * 8) =
-                        make_uint4(rx[0], ry[0], rx[1], ry[1]);
+                uint4 out = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+                if (RESID) {
+                    const uint4 rr = rrv[RESID ? ip : 0];
+                    auto add2 = [](uint32_t y2, uint32_t r2) __attribute__((always_inline)) -> uint32_t {
+                        return pack2bf(bf2f((bf16_t)(r2 & 0xffffu)) + bf2f((bf16_t)(y2 & 0xffffu)),
+                                       bf2f((bf16_t)(r2 >> 16)) + bf2f((bf16_t)(y2 >> 16)));
+                    };
+                    out = make_uint4(add2(out.x, rr.x), add2(out.y, rr.y), add2(out.z, rr.z), add2(out.w, rr.w));
+                }
+                if (m_ok) *reinterpret_cast<uint4*>(a.y + (size_t)m * a.N + nb + (kg & 1) * 16 + (kg >> 1) * 8) = out;
             } else {                                             // a pair straddling N: the narrow stores
                 const int na = nb + kg * 4;
-                if (m_ok && na < a.N) *reinterpret_cast<uint2*>(a.y + (size_t)m * a.N + na) = ta;
-                if (m_ok && na + 16 < a.N) *reinterpret_cast<uint2*>(a.y + (size_t)m * a.N + na + 16) = tb;
+                auto with_resid = [&](uint2 t, int n) __attribute__((always_inline)) -> uint2 {
+                    if (!RESID) return t;
+                    const uint2 rr = *reinterpret_cast<const uint2*>(a.resid + (size_t)m * a.N + n);
+                    return make_uint2(pack2bf(bf2f((bf16_t)(rr.x & 0xffffu)) + bf2f((bf16_t)(t.x & 0xffffu)),
+                                              bf2f((bf16_t)(rr.x >> 16)) + bf2f((bf16_t)(t.x >> 16))),
+                                      pack2bf(bf2f((bf16_t)(rr.y & 0xffffu)) + bf2f((bf16_t)(t.y & 0xffffu)),
+                                              bf2f((bf16_t)(rr.y >> 16)) + bf2f((bf16_t)(t.y >> 16))));
+                };
+                if (m_ok && na < a.N) *reinterpret_cast<uint2*>(a.y + (size_t)m * a.N + na) = with_resid(ta, na);
+                if (m_ok && na + 16 < a.N) *reinterpret_cast<uint2*>(a.y + (size_t)m * a.N + na + 16) = with_resid(tb, na + 16);
             }
         }
     }
