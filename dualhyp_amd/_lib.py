@@ -62,6 +62,7 @@ SIGNATURES = {
     "dh_quant_rows_fp8": (I, [P, P, P, I, I, P]),
     "dh_rmsnorm_quant_fp8": (I, [P, P, P, P, P, I, I, F, P, P]),
     "dh_linear_fp8": (I, [P, P, P, P, P, I, I, I, I, P, P, P, P, P, P]),
+    "dh_linear_fp8_f32": (I, [P, P, P, P, P, I, I, I, P]),
     "dh_engine_create": (I, [C.POINTER(ModelDesc), I, I, I, C.POINTER(P)]),
     "dh_engine_destroy": (None, [P]),
     "dh_engine_device_bytes": (I64, [P]),

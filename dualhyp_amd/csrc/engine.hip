@@ -216,6 +216,19 @@ int run_layers_fp8(dh_engine* e, const int64_t* ids, int n_tok, int n_seq, int m
         bf16_t* kc = e->kc + (size_t)l * e->cache_layer_elems;
         bf16_t* vtc = e->vtc + (size_t)l * e->cache_layer_elems;
         if ((rc = dh_rmsnorm_quant_fp8(e->x, W.norm_1, nullptr, e->xq, e->xscale, n_tok, d, D.norm_eps, rt, s))) return rc;
+        if (decode && n_tok <= 32) {
+            // one launch for rope + cache append + split-KV attention + combine (decode_fused.hip): the QKV product
+            // is handed over as its single fp32 "partial" (values already rounded to bf16), no LoRA (merged)
+            {
+                TimeScope t(e, 1, s);
+                if ((rc = dh_linear_fp8_f32(e->xq, e->xscale, reinterpret_cast<const uint8_t*>(W.attn_w), W.attn_ws, e->part32,
+                                            n_tok, e->qkv_dim, d, s))) return rc;
+            }
+            TimeScope t(e, 3, s);
+            if ((rc = dh_attn_decode_fused_bf16(e->part32, 1, n_seq, e->qkv_dim, 0, nullptr, 0.f, e->qkv_dim, e->qkv_dim,
+                                                D.rope_cos, D.rope_sin, seq_slot, kv_pos0, kc, vtc, e->att, H, G, hs,
+                                                e->s_max, s))) return rc;
+        } else {
         {
             TimeScope t(e, decode ? 1 : 0, s);
             if ((rc = lin(W.attn_w, W.attn_ws, e->qkv, e->qkv_dim, d, DH_EPI_PLAIN, nullptr, nullptr, nullptr))) return rc;
@@ -230,6 +243,7 @@ int run_layers_fp8(dh_engine* e, const int64_t* ids, int n_tok, int n_seq, int m
             TimeScope t(e, 2, s);
             if ((rc = dh_attn_prefill_bf16(e->qrot, kc, vtc, seq_slot, q_start, q_len, kv_pos0, e->att, nullptr, n_seq,
                                            max_q_len, H, G, hs, e->s_max, s))) return rc;
+        }
         }
         if ((rc = dh_quant_rows_fp8(e->att, e->xq, e->xscale, n_tok, d, s))) return rc;
         {

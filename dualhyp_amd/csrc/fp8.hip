@@ -62,6 +62,36 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __res
     }
 }
 
+// Few rows (a decode step): one 256-thread BLOCK per row — a single wave walks K = 14336 in 2 x 28 dependent
+// iterations (17 us for 32 rows), a block in 2 x 7.
+__global__ __launch_bounds__(256) void quant_rows_fp8_block_kernel(const bf16_t* __restrict__ x, uint8_t* __restrict__ q,
+                                                                   float* __restrict__ scale, int K) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nchunk = K >> 3;
+    const uint4* xr = reinterpret_cast<const uint4*>(x + (size_t)row * K);
+    float amax = 0.f;
+    for (int c = tid; c < nchunk; c += 256) {
+        const uint4 u = xr[c];
+        const bf16_t* p = reinterpret_cast<const bf16_t*>(&u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(bf2f(p[j])));
+    }
+    amax = wave_max(amax);
+    if (lane == 0) red[wave] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), 1e-12f);
+    const float inv = __fdiv_rn(FP8_MAX, amax);
+    if (tid == 0) scale[row] = amax * INV_FP8_MAX;
+    uint2* qr = reinterpret_cast<uint2*>(q + (size_t)row * K);
+    for (int c = tid; c < nchunk; c += 256) {
+        const uint4 u = xr[c];
+        const bf16_t* p = reinterpret_cast<const bf16_t*>(&u);
+        qr[c] = make_uint2(pack4_fp8(bf2f(p[0]) * inv, bf2f(p[1]) * inv, bf2f(p[2]) * inv, bf2f(p[3]) * inv),
+                           pack4_fp8(bf2f(p[4]) * inv, bf2f(p[5]) * inv, bf2f(p[6]) * inv, bf2f(p[7]) * inv));
+    }
+}
+
 // RMSNorm as elementwise.hip's rmsnorm_kernel (same rounding points, same Q11 flag) whose bf16 output row is
 // quantised before it leaves the registers; xn_out (nullable) still receives the bf16 row.
 template <int MAXC>
@@ -318,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(Fp8Args a) {
 // partials meet in LDS and thread t finishes output (n = t & 15, m = t >> 4).
 constexpr int ROWS = 16, NW = 8;
 
-template <int EPI, bool RESID>
+template <int EPI, bool RESID, bool OUT32 = false>
 __global__ __launch_bounds__(512, 2) void gemm_fp8_skinny_kernel(Fp8Args a) {
     constexpr bool SW = EPI == DH_EPI_SWIGLU;
     constexpr int CH = SW ? 2 : 4;                        // k-steps (32 B per lane and operand) loaded ahead per wave
@@ -405,7 +435,8 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_skinny_kernel(Fp8Args a) {
         o = fp8_finish<EPI>(s, xs * a.ws[nn], a, nn);
         if (RESID) o = bf2f(a.resid[(size_t)tm * a.N + nn]) + o;
     }
-    a.y[(size_t)tm * a.N + nn] = f2bf(o);
+    if (OUT32) reinterpret_cast<float*>(a.y)[(size_t)tm * a.N + nn] = o;     // bf16-exact value as fp32 (fused decode consumer)
+    else a.y[(size_t)tm * a.N + nn] = f2bf(o);
 }
 
 template <int EPI, bool RESID, int NST>
@@ -438,7 +469,10 @@ int launch_skinny(const Fp8Args& a, hipStream_t s) {
 extern "C" int dh_quant_rows_fp8(const dh_bf16* x, uint8_t* q, float* scale, int rows, int K, void* stream) {
     DH_CHECK(x && q && scale && rows >= 0 && K > 0 && K % 8 == 0, "dh_quant_rows_fp8: bad argument (K %% 8 must be 0)");
     if (rows == 0) return 0;
-    hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, q, scale, rows, K);
+    if (rows <= 256)
+        hipLaunchKernelGGL(quant_rows_fp8_block_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, q, scale, K);
+    else
+        hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, q, scale, rows, K);
     DH_LAUNCH_CHECK();
     return 0;
 }
@@ -456,6 +490,16 @@ extern "C" int dh_rmsnorm_quant_fp8(const dh_bf16* x, const dh_bf16* w, dh_bf16*
     else if (d <= 4096) { LAUNCH(8); }
     else { LAUNCH(16); }
 #undef LAUNCH
+    DH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dh_linear_fp8_f32(const uint8_t* xq, const float* x_scale, const uint8_t* wq, const float* w_scale, float* y32,
+                                 int M, int N, int K, void* stream) {
+    DH_CHECK(xq && x_scale && wq && w_scale && y32, "dh_linear_fp8_f32: null operand");
+    DH_CHECK(M >= 1 && M <= 32 && N > 0 && K > 0 && K % 128 == 0, "dh_linear_fp8_f32: needs 1 <= M <= 32 and K %% 128 == 0 (M=%d K=%d)", M, K);
+    Fp8Args a{xq, wq, nullptr, reinterpret_cast<bf16_t*>(y32), x_scale, w_scale, nullptr, nullptr, nullptr, nullptr, M, N, K, 0, 0};
+    hipLaunchKernelGGL((gemm_fp8_skinny_kernel<DH_EPI_PLAIN, false, true>), dim3(cdiv(N, ROWS)), dim3(512), 0, (hipStream_t)stream, a);
     DH_LAUNCH_CHECK();
     return 0;
 }

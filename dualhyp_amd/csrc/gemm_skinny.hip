@@ -369,11 +369,11 @@ int launch_rows_ng(const bf16_t* x, const bf16_t* w, const bf16_t* w_ext, float*
     if (M <= 32) return launch_rows<KPS, 1, 1>(x, w, w_ext, y32, M, n_main, N, K, ksplit, s);
     if (M <= 64) return launch_rows<KPS, 2, 1>(x, w, w_ext, y32, M, n_main, N, K, ksplit, s);
     if (M <= 128) return launch_rows<KPS, 4, 1>(x, w, w_ext, y32, M, n_main, N, K, ksplit, s);
-    // CT > 1 (several column tiles per wave, one x fragment read feeding CT MFMAs; same bits) was measured at 640 rows:
-    // no change (6.44 vs 6.45 ms per decode step) — the kernel is bound by the partial-sum stores and the x staging, not
-    // by the fragment reads — so one tile per wave stays the default; dh_set_tuning(11, ct) selects the others
+    // more than 128 rows: two column tiles per wave — one x fragment read feeds two MFMAs, same bits.  Measured on one
+    // box at 640 rows (decode step): CT 1 6.46 ms, CT 2 6.20-6.26 ms, CT 4 6.41 ms (its 180 VGPRs cost more than the
+    // saved LDS reads); dh_set_tuning(11, ct) overrides
     constexpr int CTMAX = KPS == 8 ? 4 : 2;               // W fragments: CT * KPS * 4 VGPRs
-    const int ct = g_rows_ct ? g_rows_ct : 1;
+    const int ct = g_rows_ct ? g_rows_ct : 2;
     if (ct >= 4 && CTMAX >= 4) return launch_rows<KPS, 8, CTMAX>(x, w, w_ext, y32, M, n_main, N, K, ksplit, s);
     if (ct >= 2) return launch_rows<KPS, 8, 2>(x, w, w_ext, y32, M, n_main, N, K, ksplit, s);
     return launch_rows<KPS, 8, 1>(x, w, w_ext, y32, M, n_main, N, K, ksplit, s);

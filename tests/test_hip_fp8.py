@@ -89,7 +89,7 @@ def test_linear_fp8_matches_the_oracle(M, N, K):
     chk(ops.linear_fp8(xq, xs, wqd, wsd, epilogue=ops.EPI_SWIGLU, w2q=w2qd, w2_scale=w2sd), F.silu(y0) * O.linear_fp8(x, w2q, w2s.view(-1)), "swiglu",
         max_ulp=4, max_frac=0.025)      # a product of two rounded values: their boundary flips add up
     sc, bi = (1 + U((N,), 0.5, "fs").float()).bfloat16(), U((N,), 0.5, "fb")
-    chk(ops.linear_fp8(xq, xs, wqd, wsd, epilogue=ops.EPI_ADAPTER, scale=dv(sc), bias=dv(bi)), sc * (y0 + bi), "adapter", floor=1.0)    # y0 + bias cancels: ulps at max(|a|, |b|, rms)
+    chk(ops.linear_fp8(xq, xs, wqd, wsd, epilogue=ops.EPI_ADAPTER, scale=dv(sc), bias=dv(bi)), sc * (y0 + bi), "adapter", floor=1.0, max_ulp=4)    # y0 + bias cancels: ulps at max(|a|, |b|, rms)
 
 
 def rel_rms(a, b):
