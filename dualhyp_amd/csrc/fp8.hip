@@ -12,6 +12,9 @@
 //   gemm_fp8_kernel             M > 32: 128 x 128 x 128 tiles, both operands through LDS (global_load_lds 16 B, rows
 //                               of 128 B with the source-side XOR swizzle of gemm.hip), 4 waves x (4 x 4) MFMA tiles
 //   gemm_fp8_skinny_kernel      M <= 32 (decode): W streamed HBM -> VGPR once, K dealt over the 8 waves of a block
+// Tried and dropped: a port of gemm256.hip's 256 x 256 ping-pong kernel to v_mfma_scale_f32_32x32x64_f8f6f4 (operand map
+// verified with integers: lane l = row l & 31, k 32 (l >> 5) ..+32).  With two fragment sets it spills (128 accumulator
+// + 2 x 48 fragment registers: 0.57 PFLOP/s), with one set it reaches 1.15 PFLOP/s against 1.5 for the 128-tile kernel.
 // MFMA operand map (checked with integer data, tests/test_hip_fp8.py): lane l holds the 32 consecutive k
 // [32 (l >> 4), 32 (l >> 4) + 32) of row (A) / column (B) l & 15 — one MX block per lane, hence one scale per lane.
 #include "common.h"

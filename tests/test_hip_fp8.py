@@ -192,3 +192,4 @@ def test_fp8_llama3_shape_vs_reference(golden):
     free = generate(m, t["idx"].to(DEV), T + G, temperature=0.2, top_k=1).cpu()
     record_parity("fp8_decoder.llama3_shape.generate_ids", generated=G, equal_to_reference=int((free[T:] == ids[T:]).sum()))
     assert torch.equal(free, ids)
+
