@@ -94,6 +94,34 @@ def test_forward_nocache_and_cache(golden, name):
                 assert rel_rms(ld[0, 0], t["bf16.logits_decode"][s]) < 3e-2
 
 
+def test_cached_forward_with_grad_enabled(golden):
+    """`model(x, input_pos)` OUTSIDE torch.no_grad() — the reference allows it, and requires_grad=True is the
+    nn.Module default that .eval() does not change — is incremental decoding through the KV cache, not a training
+    forward from position 0; a model without LoRA (r = 0) with grad enabled is plain inference."""
+    t, meta = golden("tiny_r4")
+    cfg, m = build(meta)
+    assert any(p.requires_grad for p in m.parameters())
+    T = meta["T"]
+    x = t["idx0"].view(1, -1).to(DEV)
+    tok = torch.tensor([[int(t["bf16.decode_tokens"][0])]], device=DEV)
+    with torch.no_grad():
+        want_p = m(x, torch.arange(T, device=DEV))
+        want_d = m(tok, torch.tensor([T], device=DEV))
+        m.reset_cache()
+    got_p = m(x, torch.arange(T, device=DEV))                  # grad mode on
+    got_d = m(tok, torch.tensor([T], device=DEV))
+    assert torch.equal(got_p, want_p) and torch.equal(got_d, want_d) and not got_d.requires_grad
+    m.reset_cache()
+    cfg0 = Config(**{**meta["config"], "r": 0})
+    sd0 = {k: v for k, v in synth_state_dict(cfg0, seed=meta["seed"], norm_jitter=0.25, weight_scale=4.0, device=DEV).items()}
+    m0 = GPT(cfg0).to(device=DEV, dtype=torch.bfloat16)
+    m0.load_state_dict(sd0, strict=True)
+    m0.eval()
+    lg = m0(x)                                                  # grad enabled, nothing trainable: inference path
+    with torch.no_grad():
+        assert torch.equal(lg, m0(x))
+
+
 @pytest.mark.parametrize("name", TINY)
 def test_generate_ids(golden, name):
     t, meta = golden(name)

@@ -193,3 +193,36 @@ def test_flat_bucket_allreduce_gloo():
         assert p.exitcode == 0
     for _, g0, g1 in got:
         assert torch.all(g0 == 1.5) and torch.all(g1 == 15.0)       # mean over the two ranks
+
+
+def test_byte_tokenizer_and_reliability_tokens():
+    from dualhyp_amd.tokenizer import ByteTokenizer, load_tokenizer
+    tok = ByteTokenizer()
+    ids = tok.encode("héllo\n</s>")
+    assert ids[0] == tok.bos_token_id and ids[-1] == tok.eos_token_id and tok.decode(ids) == "héllo\n"
+    tok.add_reliability_tokens(320)
+    ids = tok.encode("a<<C>><<N>><<M>>b")
+    assert ids == [1, ord("a") + 3, 320, 322, 321, ord("b") + 3] and tok.decode(ids) == "ab"
+    # the reference's answer extraction works on the decoded text of prompt and prompt+continuation
+    p = tok.encode("### Response:\n")
+    full = p + tok.encode("the cat sat\nmore")[1:]
+    assert extract_answer(tok.decode(full), tok.decode(p)) == "the cat sat"
+    assert isinstance(load_tokenizer("/nonexistent-dir", "byte"), ByteTokenizer)
+    with pytest.raises(FileNotFoundError):
+        load_tokenizer("/nonexistent-dir", "hf")
+
+
+def test_harness_flags_are_the_references():
+    """python -m dualhyp_amd.inference / .finetune accept every flag of inference/ger.py:129-153 and
+    finetune/ger.py:373-407 (parsed here without touching the GPU: argparse runs before anything else)."""
+    import argparse
+    import dualhyp_amd.inference as inf
+    p = argparse.ArgumentParser()
+    inf.add_lora_arguments(p)
+    a = p.parse_args(["--lora_r", "8", "--lora_alpha", "32", "--lora_dropout", "0.1"])
+    assert (a.lora_r, a.lora_alpha, a.lora_dropout, a.lora_query, a.lora_mlp) == (8, 32, 0.1, True, False)
+    a.llm_checkpoint, a.config_name = "checkpoints/TinyLlama/tiny-llama-1.1b-chat", None
+    cfg = inf.config_from_args(a)
+    assert cfg.name == "tiny-llama-1.1b-chat" and cfg.r == 8 and cfg.alpha == 32 and cfg.to_projection and not cfg.to_mlp
+    a.llm_checkpoint = "checkpoints/meta-llama/Llama-3-8B"
+    assert inf.config_from_args(a).block_size == 4096          # inference/ger.py:189-190

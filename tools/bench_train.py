@@ -2,7 +2,7 @@
 """LoRA fine-tune micro-step timing at the TinyLlama-1.1B shape (BASELINE configs[2] unit of work):
 T = 560 tokens (512 masked prompt + 47 response + EOS), micro-batch 1, fwd + bwd, chunked CE."""
 import sys, time, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from dualhyp_amd import GPT, Config, GER_LORA
 from dualhyp_amd.synth import synth_state_dict, synth_prompts
 from dualhyp_amd.train import prepare_for_training

@@ -3,7 +3,7 @@
 times each and nothing else: the workload for the rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE),
 which take minutes on the full bench.  Weights rotate so every launch streams them from HBM."""
 import sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from dualhyp_amd import ops
 D = "cuda:0"
 M, d, I, r = 2 * 32 * 512, 2048, 5632, 16     # two batches per prefill launch, as bench.py runs
