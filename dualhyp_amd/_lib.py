@@ -43,6 +43,7 @@ SIGNATURES = {
     "dh_rmsnorm_bf16": (I, [P, P, P, P, P, I, I, F, P, P]),
     "dh_qkv_rope_cache_bf16": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "dh_linear_bf16": (I, [P, P, P, I, I, I, I, P, P, I, P, F, I, I, P, P, P, P]),
+    "dh_linear_qkv_rope_cache_bf16": (I, [P, P, I, I, P, I, P, F, P, P, P, P, P, P, P, I, I, I, I, P]),
     "dh_linear_partial_bf16": (I, [P, P, P, P, I, I, I, I, I, P]),
     "dh_linear_chain_bf16": (I, [P, P, P, P, I, I, I, I, I, P]),
     "dh_finish_norm_bf16": (I, [P, I, I, I, I, P, F, P, P, P, P, F, P, P]),

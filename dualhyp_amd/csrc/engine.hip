@@ -26,6 +26,7 @@ constexpr int MAX_DECODE_ROWS = 2048;  // single-token calls up to here take the
 // k order) instead of the K-sliced streaming kernels: from a few hundred rows on the step is no longer weight-
 // bandwidth-bound and the partial-sum traffic of the K slices dominates (dh_set_tuning key 10; 0 = never).
 int g_decode_tiled_rows = 0;
+int g_fuse_qkv_rope = 1;   // dh_set_tuning key 12: 0 = QKV GEMM, then dh_qkv_rope_cache_bf16 (the two-step form)
 
 struct dh_engine {
     dh_model_desc d;
@@ -151,9 +152,19 @@ int run_layers(dh_engine* e, const int64_t* ids, int n_tok, int n_seq, int max_q
         bf16_t* kc = e->kc + (size_t)l * e->cache_layer_elems;
         bf16_t* vtc = e->vtc + (size_t)l * e->cache_layer_elems;
         if ((rc = dh_rmsnorm_bf16(e->x, nullptr, W.norm_1, e->xn, nullptr, n_tok, d, D.norm_eps, rt, s))) return rc;
-        if (W.attn_lora_a) {
+        // large packed prefills: rope + KV append ride in the QKV GEMM's epilogue (same bits, no pass over the qkv tensor)
+        const bool fuse_qkv = !decode && g_fuse_qkv_rope && dh_linear_is_big(n_tok, e->qkv_dim, DH_EPI_LORA);
+        if (W.attn_lora_a)
             if ((rc = linear(e, e->xn, W.attn_lora_a, e->xa, n_tok, 48, d, DH_EPI_PLAIN, nullptr, nullptr, 0, nullptr, 0, 0,
                              nullptr, nullptr, nullptr, s, false))) return rc;
+        if (fuse_qkv) {
+            TimeScope t(e, 0, s);
+            if ((rc = dh_linear_qkv_rope_cache_bf16(e->xn, W.attn_w, n_tok, d, W.attn_lora_a ? e->xa : nullptr, 48,
+                                                    W.attn_lora_a ? W.attn_lora_b : nullptr, D.lora_scale, D.rope_cos,
+                                                    D.rope_sin, e->tok_slot, e->tok_pos, e->qrot, kc, vtc, H, G, hs,
+                                                    e->s_max, s))) return rc;
+        } else {
+        if (W.attn_lora_a) {
             if ((rc = linear(e, e->xn, W.attn_w, e->qkv, n_tok, e->qkv_dim, d, DH_EPI_LORA, nullptr, e->xa, 48,
                              W.attn_lora_b, d, d + e->kv_dim, nullptr, nullptr, nullptr, s, true))) return rc;
         } else {
@@ -162,6 +173,7 @@ int run_layers(dh_engine* e, const int64_t* ids, int n_tok, int n_seq, int max_q
         }
         if ((rc = dh_qkv_rope_cache_bf16(e->qkv, D.rope_cos, D.rope_sin, e->tok_slot, e->tok_pos, e->qrot, kc, vtc, nullptr,
                                          nullptr, n_tok, H, G, hs, e->s_max, s))) return rc;
+        }
         if (decode) {
             TimeScope t(e, 3, s);
             if ((rc = dh_attn_decode_bf16(e->qrot, kc, vtc, seq_slot, kv_pos0, e->att, e->dec_work, n_seq, H, G, hs,

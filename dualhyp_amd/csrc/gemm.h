@@ -17,7 +17,19 @@ struct GemmArgs {
     float lora_scale;
     int nb_n, nb_m;
     int gm;            // m-tiles per band of the 256-tile kernel's block order
+    // DH_EPI_QKV (256-tile kernel only): the fused-QKV projection whose epilogue also rotates q / k, writes q and
+    // appends k / v to the KV cache (what dh_qkv_rope_cache_bf16 does in a separate pass over the qkv tensor)
+    const bf16_t* rope_cos;
+    const bf16_t* rope_sin;
+    const int32_t* tok_slot;
+    const int32_t* tok_pos;
+    bf16_t* q_out;
+    bf16_t* k_cache;
+    bf16_t* vT_cache;
+    int n_head, n_groups, hs, s_max;
 };
+
+constexpr int DH_EPI_QKV = 4;   // internal: LoRA (optional) + rope + cache append, see dh_linear_qkv_rope_cache_bf16
 
 
 
@@ -36,6 +48,9 @@ bool dh_chain_ok(int M, int n_main, int n_ext, int K, int ksplit);
 int dh_chain_tiled(const bf16_t* x, const bf16_t* w, const bf16_t* w_ext, float* y32, int M, int n_main, int n_ext, int K,
                    int kps, hipStream_t s);
 extern int g_dt_min_rows, g_chain_min_rows;
+
+// true when dh_linear_impl would send this shape to the 256-tile kernel (gemm256.hip)
+bool dh_linear_is_big(int M, int N, int epilogue);
 
 // M >= 256: 256 x 256 x 64 tiles, one block per CU (gemm256.hip)
 int dh_linear_256(GemmArgs a, int epilogue, hipStream_t s);

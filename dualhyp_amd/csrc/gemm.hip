@@ -256,6 +256,29 @@ extern "C" int dh_linear_bf16(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, in
                           resid, g_linear_phase, (hipStream_t)stream);
 }
 
+bool dh_linear_is_big(int M, int N, int epilogue) {
+    const int tiles256 = cdiv(M, 256) * cdiv(N, epilogue == DH_EPI_SWIGLU ? 128 : 256);
+    return g_gemm_variant >= 1 && M >= 256 && N >= (epilogue == DH_EPI_SWIGLU ? 128 : 256) && tiles256 >= 128;
+}
+
+extern "C" int dh_linear_qkv_rope_cache_bf16(const dh_bf16* x, const dh_bf16* w, int M, int K, const dh_bf16* xa, int xa_ld,
+                                             const dh_bf16* lora_b, float lora_scale, const dh_bf16* cos, const dh_bf16* sin,
+                                             const int32_t* tok_slot, const int32_t* tok_pos, dh_bf16* q_out, dh_bf16* k_cache,
+                                             dh_bf16* vT_cache, int n_head, int n_groups, int hs, int s_max, void* stream) {
+    DH_CHECK(x && w && cos && sin && tok_slot && tok_pos && q_out && k_cache && vT_cache, "dh_linear_qkv_rope_cache_bf16: null argument");
+    DH_CHECK(hs == 64 || hs == 128, "dh_linear_qkv_rope_cache_bf16: head_size %d unsupported", hs);
+    DH_CHECK(n_groups > 0 && n_head % n_groups == 0 && K % BK == 0, "dh_linear_qkv_rope_cache_bf16: bad shape");
+    const int N = (n_head + 2 * n_groups) * hs, d = n_head * hs, kv = n_groups * hs;
+    DH_CHECK(dh_linear_is_big(M, N, DH_EPI_LORA), "dh_linear_qkv_rope_cache_bf16: M=%d is below the 256-tile kernel's range; use dh_linear_bf16 + dh_qkv_rope_cache_bf16", M);
+    DH_CHECK(lora_b == nullptr || (xa && xa_ld >= 48 && xa_ld % 8 == 0), "dh_linear_qkv_rope_cache_bf16: LoRA needs xa [M, >=48]");
+    GemmArgs a{};
+    a.x = x; a.w = w; a.xa = xa; a.lora_b = lora_b; a.M = M; a.N = N; a.K = K; a.xa_ld = xa_ld; a.split0 = d; a.split1 = d + kv;
+    a.lora_scale = lora_scale;
+    a.rope_cos = cos; a.rope_sin = sin; a.tok_slot = tok_slot; a.tok_pos = tok_pos; a.q_out = q_out; a.k_cache = k_cache;
+    a.vT_cache = vT_cache; a.n_head = n_head; a.n_groups = n_groups; a.hs = hs; a.s_max = s_max;
+    return dh_linear_256(a, DH_EPI_QKV, (hipStream_t)stream);
+}
+
 int dh_linear_impl(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N, int K, int epilogue,
                    const dh_bf16* w2, const dh_bf16* xa, int xa_ld, const dh_bf16* lora_b, float lora_scale,
                    int split0, int split1, const dh_bf16* vec_a, const dh_bf16* vec_b, const dh_bf16* resid,
@@ -277,8 +300,7 @@ int dh_linear_impl(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N,
     const bool skinny = (kernel == 0 || kernel == 2) && M <= 32 && K % 32 == 0;   // weight-streaming kernel (gemm_skinny.hip)
     // the 256-tile kernel runs one block per CU: below ~half a chip of tiles (a training micro-batch, M ~ 560)
     // the 128-tile kernel puts four times the blocks in flight and wins
-    const int tiles256 = cdiv(M, 256) * cdiv(N, epilogue == DH_EPI_SWIGLU ? 128 : 256);
-    const bool big = !skinny && g_gemm_variant >= 1 && M >= 256 && N >= (epilogue == DH_EPI_SWIGLU ? 128 : 256) && tiles256 >= 128;
+    const bool big = !skinny && dh_linear_is_big(M, N, epilogue);
     if (big) {
         if (epilogue == DH_EPI_LORA) {
             DH_CHECK(xa && lora_b && xa_ld >= 16 && xa_ld % 8 == 0, "dh_linear_bf16: LORA epilogue needs xa/lora_b");

@@ -115,6 +115,25 @@ def qkv_rope_cache(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, tok_
     return q
 
 
+def linear_qkv_rope_cache(x: torch.Tensor, w: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, tok_slot: torch.Tensor,
+                          tok_pos: torch.Tensor, k_cache: torch.Tensor, vT_cache: torch.Tensor, n_head: int, n_groups: int,
+                          xa: Optional[torch.Tensor] = None, lora_b: Optional[torch.Tensor] = None,
+                          lora_scale: float = 1.0) -> torch.Tensor:
+    """QKV projection (+LoRA) with rope and KV-cache append in the GEMM epilogue -> rotated q [M, n_head, hs];
+    dh_linear_qkv_rope_cache_bf16 (large M only)."""
+    k = _Keep()
+    x = _dev(x, name="x")
+    K = x.size(-1)
+    M = x.numel() // K
+    hs, s_max = k_cache.size(-1), k_cache.size(-2)
+    q = torch.empty((M, n_head, hs), dtype=torch.bfloat16, device=x.device)
+    check(_lib.load().dh_linear_qkv_rope_cache_bf16(_p(x), k(w, name="w"), M, K, k(xa, name="xa"), 0 if xa is None else xa.size(-1),
+                                                    k(lora_b, name="lora_b"), float(lora_scale), k(cos), k(sin),
+                                                    k(tok_slot, torch.int32), k(tok_pos, torch.int32), _p(q), _p(k_cache),
+                                                    _p(vT_cache), n_head, n_groups, hs, s_max, _stream()))
+    return q
+
+
 def attn_prefill(q: torch.Tensor, k_cache: torch.Tensor, vT_cache: torch.Tensor, seq_slot: torch.Tensor,
                  q_start: torch.Tensor, q_len: torch.Tensor, kv_pos0: torch.Tensor, max_q_len: int,
                  lse: Optional[torch.Tensor] = None) -> torch.Tensor:

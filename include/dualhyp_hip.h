@@ -94,6 +94,17 @@ int dh_linear_bf16(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N,
                    const dh_bf16* vec_a, const dh_bf16* vec_b, const dh_bf16* resid,
                    void* stream);
 
+/* The fused-QKV projection of a packed prefill with the work of dh_qkv_rope_cache_bf16 in its epilogue
+ * (ger/model.py:216-259 after ger/lora.py:367-402): q/k rotated, q -> q_out [M, n_head, hs], k / v appended to the
+ * caches; the [M, (n_head+2g)*hs] qkv tensor is never written.  Same arithmetic and rounding points as
+ * dh_linear_bf16(EPI_LORA, splits (d, d+g*hs)) followed by dh_qkv_rope_cache_bf16 — bit-identical results.
+ * lora_b NULL = no LoRA.  Only for shapes the 256-tile kernel takes (M >= 256 and >= 128 tiles); smaller calls use the
+ * two-step form. */
+int dh_linear_qkv_rope_cache_bf16(const dh_bf16* x, const dh_bf16* w, int M, int K, const dh_bf16* xa, int xa_ld,
+                                  const dh_bf16* lora_b, float lora_scale, const dh_bf16* cos, const dh_bf16* sin,
+                                  const int32_t* tok_slot, const int32_t* tok_pos, dh_bf16* q_out, dh_bf16* k_cache,
+                                  dh_bf16* vT_cache, int n_head, int n_groups, int hs, int s_max, void* stream);
+
 /* fp32 partial sums for the fused decode consumers below (M <= 4096 rows, weight streaming):
  *   y32[p][m][n] = sum over K-slice p of x[m,:] . W'[n,:],  W' = [w (n_main rows) ; w_ext (n_ext rows)]
  * y32: [ksplit][M][n_main+n_ext] fp32.  w_ext is the rank-padded LoRA A (so x·A^T comes out of the

@@ -137,6 +137,43 @@ def test_linear_tile_size_invariant(dev):
     assert torch.equal(ops.linear(xt, w)[-300:], ops.linear(xt[-300:].contiguous(), w))
 
 
+@pytest.mark.parametrize("hs,n_head,n_groups,lora", [(64, 32, 4, True), (128, 32, 8, True), (64, 32, 4, False)])
+def test_qkv_gemm_with_rope_and_cache_epilogue(dev, hs, n_head, n_groups, lora):
+    """dh_linear_qkv_rope_cache_bf16 (rope + KV append inside the 256-tile QKV GEMM's epilogue) against the two-step
+    form dh_linear_bf16(EPI_LORA) + dh_qkv_rope_cache_bf16 on a packed ragged batch: rotated q and both caches bit for bit."""
+    from dualhyp_amd import ops
+    from oracle import ger_oracle as O
+    d = n_head * hs
+    kv = n_groups * hs
+    N = d + 2 * kv
+    lens = [512] * 30 + [300, 212, 640, 384]                       # 16384 packed tokens, ragged tail
+    M, s_max = sum(lens), 640
+    x = U((M, d), 1.0, f"rq{hs}").to(dev)
+    w = U((N, d), 0.03, f"rw{hs}").to(dev)
+    A48, B16 = U((48, d), 1 / math.sqrt(d), f"ra{hs}").to(dev), U((N, 16), 0.05, f"rb{hs}").to(dev)
+    cos, sin = O.build_rope_cache(s_max, hs)
+    cos, sin = cos.to(dev), sin.to(dev)
+    i32 = torch.int32
+    slot = torch.cat([torch.full((n,), i, dtype=i32) for i, n in enumerate(lens)]).to(dev)
+    pos = torch.cat([torch.arange(n, dtype=i32) for n in lens]).to(dev)
+    B = len(lens)
+    mk = lambda: (torch.zeros((B, n_groups, s_max, hs), dtype=torch.bfloat16, device=dev),
+                  torch.zeros((B, n_groups, hs, s_max), dtype=torch.bfloat16, device=dev))
+    kc1, vt1 = mk()
+    kc2, vt2 = mk()
+    xa = ops.linear(x, A48) if lora else None
+    if lora:
+        qkv = ops.linear(x, w, epilogue=ops.EPI_LORA, xa=xa, lora_b=B16, lora_scale=2.0, splits=(d, d + kv))
+    else:
+        qkv = ops.linear(x, w)
+    q1 = ops.qkv_rope_cache(qkv, cos, sin, slot, pos, kc1, vt1, n_head, n_groups)
+    q2 = ops.linear_qkv_rope_cache(x, w, cos, sin, slot, pos, kc2, vt2, n_head, n_groups, xa=xa, lora_b=B16 if lora else None, lora_scale=2.0)
+    assert torch.equal(q1, q2), "rotated q differs"
+    assert torch.equal(kc1, kc2), "K cache differs"
+    assert torch.equal(vt1, vt2), "V^T cache differs"
+    assert float(kc2.float().abs().sum()) > 0 and float(vt2.float().abs().sum()) > 0
+
+
 @pytest.mark.parametrize("M,d,I", [(50, 256, 384), (200, 2048, 5632), (300, 256, 384), (515, 2048, 5632)])
 def test_linear_swiglu_and_adapter(dev, M, d, I):
     from dualhyp_amd import ops
