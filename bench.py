@@ -46,6 +46,12 @@ WORKLOADS = {
                            what="DualHyp inference, Llama-3-8B bf16 + LoRA r16, batch 32/GPU synthetic 10+10-hyp prompts, 1536-token prompt -> 64 tokens, greedy",
                            metric="corrected utterances/sec (Llama-3-8B, 10+10 hyps, 1536->64 tok)", dtype="bf16",
                            kernel="gemm_nt256_kernel (prefill GEMMs)"),
+    "finetune-tinyllama": dict(model="tiny-llama-1.1b-chat", prompt=560, fp8=False, peak=2500.0, in_flight=1, prefill_batches=1, train=True,
+                               what="DualHyp LoRA fine-tune (finetune/ger.py --dual_hypotheses), TinyLlama-1.1B bf16 base + fp32 LoRA masters r16, "
+                                    "micro-batch 1 x 560 tokens (512 masked prompt + 47 response + EOS), optimizer step = 32 utterances "
+                                    "shared by the ranks, one flat-bucket all-reduce of the LoRA gradients per step, AdamW",
+                               metric="fine-tuned utterances/sec (TinyLlama-1.1B LoRA r16, T=560, global batch 32)", dtype="bf16",
+                               kernel="whole micro-step (forward + chunked CE + backward, one hipGraph replay)"),
     "llama3-8b-fp8": dict(model="Llama-3-8B", prompt=1536, fp8=True, peak=5000.0, in_flight=4, prefill_batches=1,
                           what="DualHyp inference, Llama-3-8B with merged LoRA, fp8 e4m3 weights (per-channel scales) and per-token fp8 "
                                "activations, batch 32/GPU synthetic 10+10-hyp prompts, 1536-token prompt -> 64 tokens, greedy",
@@ -187,6 +193,8 @@ def main() -> None:
     model.load_state_dict(sd, strict=True)
     del sd
     model.eval()
+    if wl.get("train"):
+        return bench_finetune(a, wl, cfg, model, dev, rank, world, rehearsal)
     if wl["fp8"]:
         from dualhyp_amd import quantize_model_fp8
         quantize_model_fp8(model)                  # merge_lora_weights, then e4m3 rows + channel scales
@@ -345,6 +353,84 @@ def main() -> None:
         result["parity"] = parity_vs_oracle(model, timed_prompts[0], outs[0][0], ref, gen_kw)
     if rank == 0:
         print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_finetune(a, wl, cfg, model, dev, rank: int, world: int, rehearsal: bool) -> None:
+    """BASELINE configs[2]: data-parallel LoRA fine-tune.  A step = ONE optimizer step over a global batch of 32
+    utterances (finetune/ger.py:381: batch_size 32, micro_batch_size 1): every rank runs 32 / world micro-steps
+    (GraphedTrainStep: forward + chunked CE + backward as one hipGraph replay, gradients accumulated into the flat fp32
+    bucket), then ONE all-reduce of the bucket (RCCL over xGMI when world > 1), AdamW on the fp32 LoRA masters.  Total
+    work per step is fixed, so `scaling` is "strong"."""
+    import torch.distributed as dist
+    from dualhyp_amd.finetune import FlatGradBucket
+    from dualhyp_amd.synth import synth_prompts
+    from dualhyp_amd.train import GraphedTrainStep, prepare_for_training
+    T, GLOBAL = wl["prompt"], 32
+    assert GLOBAL % world == 0, "--gpus must divide the global batch of 32"
+    per_rank = GLOBAL // world
+    model.train()
+    params = prepare_for_training(model)
+    bucket = FlatGradBucket(params)
+    opt = torch.optim.AdamW(params, lr=1e-4, weight_decay=0.02)
+    step_fn = GraphedTrainStep(model, bucket)
+    n_steps = a.steps + max(a.warmup, 1)
+    corpus = synth_prompts(GLOBAL * 2, T, cfg.padded_vocab_size, seed=1337)
+    mine = [p.view(1, -1).to(dev) for p in corpus[rank::world]]
+
+    def labels_of(ids):
+        lab = ids.clone()
+        lab[:, :512] = -1
+        return lab
+    labs = [labels_of(p) for p in mine]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def opt_step(k):
+        loss = None
+        for i in range(per_rank):
+            j = (k * per_rank + i) % len(mine)
+            loss = step_fn(mine[j], labs[j], 1.0 / GLOBAL)
+        bucket.all_reduce_mean()
+        opt.step()
+        bucket.zero()
+        return loss
+    for k in range(max(a.warmup, 1)):
+        opt_step(k)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        last = opt_step(k)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device="cpu" if rehearsal else dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        # SURVEY §8d: fwd 2NT + dX 2NT over the frozen base (no dW), LoRA 6 x 4.5M x T, attention fwd+bwd
+        d, I = cfg.n_embd, cfg.intermediate_size
+        qkv = (cfg.n_head + 2 * cfg.n_query_groups) * cfg.head_size
+        n_lin = cfg.n_layer * d * (qkv + d + 3 * I) + cfg.padded_vocab_size * d
+        n_lora = cfg.n_layer * (64 * d + 16 * (qkv + d))
+        attn = 3.5 * cfg.n_layer * 4 * cfg.n_head * cfg.head_size * (T * (T + 1) / 2)
+        flop_utt = 4.0 * n_lin * T + 6.0 * n_lora * T + attn
+        utt = GLOBAL * a.steps
+        achieved = flop_utt * utt / dt / 1e12 / world          # per GPU
+        print(json.dumps({
+            "metric": wl["metric"], "value": utt / dt, "unit": "utterances/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": wl["dtype"],
+            "data": "synthetic",
+            "config": {"workload": wl["what"], "global_batch": GLOBAL, "micro_batches_per_rank_per_step": per_rank, "tokens": T,
+                       "parallelism": f"data-parallel x{world}, flat LoRA-gradient bucket of {bucket.flat.numel()} fp32 elements"},
+            "roofline": {"bound": "mfma", "kernel": wl["kernel"], "achieved": achieved, "peak": wl["peak"], "unit": "TFLOP/s",
+                         "frac": achieved / wl["peak"], "traffic": None, "flop_per_utterance": flop_utt,
+                         "note": "algorithmic FLOP of the whole micro-step / wall time per GPU: kernels inside a hipGraph replay cannot be bracketed by events"},
+            "last_loss": float(last.item()), "cpu_baseline": None}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
