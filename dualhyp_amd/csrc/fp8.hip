@@ -8,7 +8,7 @@
 // arithmetic is restated on the CPU in oracle/ger_oracle.py (quantize_rows_fp8 / linear_fp8) with torch's e4m3fn type.
 //
 //   quant_rows_fp8_kernel       bf16 rows -> e4m3 rows + one fp32 scale per row (one wave per row, two passes)
-//   rmsnorm_quant_fp8_kernel    RMSNorm (ger/rmsnorm.py:17-21, bf16 rounding points) with the quantisation fused
+//   rmsnorm_quant_fp8_block_kernel  RMSNorm (ger/rmsnorm.py:17-21, bf16 rounding points) with the quantisation fused
 //   gemm_fp8_kernel             M > 32: 128 x 128 x 128 tiles, both operands through LDS (global_load_lds 16 B, rows
 //                               of 128 B with the source-side XOR swizzle of gemm.hip), 4 waves x (4 x 4) MFMA tiles
 //   gemm_fp8_skinny_kernel      M <= 32 (decode): W streamed HBM -> VGPR once, K dealt over the 8 waves of a block
@@ -95,24 +95,31 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_block_kernel(const bf16_t*
     }
 }
 
-// RMSNorm as elementwise.hip's rmsnorm_kernel (same rounding points, same Q11 flag) whose bf16 output row is
-// quantised before it leaves the registers; xn_out (nullable) still receives the bf16 row.
-template <int MAXC>
-__global__ __launch_bounds__(256) void rmsnorm_quant_fp8_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
-                                                                bf16_t* __restrict__ xn_out, uint8_t* __restrict__ q,
-                                                                float* __restrict__ scale, int rows, int d, float eps,
-                                                                const uint8_t* __restrict__ row_tail) {
-    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (row >= rows) return;
+// RMSNorm with elementwise.hip's rounding points and Q11 flag (ger/rmsnorm.py:17-21) whose bf16 output row is quantised
+// before it leaves the registers; xn_out (nullable) still receives the bf16 row.  One 256-thread block per row (16
+// elements per thread at d = 4096) for every row count, so a row's sum of squares is added up in the same order in a
+// 32-row decode step and in a 49 152-row prefill (a wave-per-row version took 10.7 us for 32 rows: three dependent
+// memory phases of a single wave).
+template <int EPT>
+__global__ __launch_bounds__(256) void rmsnorm_quant_fp8_block_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                                      bf16_t* __restrict__ xn_out, uint8_t* __restrict__ q,
+                                                                      float* __restrict__ scale, int d, float eps,
+                                                                      const uint8_t* __restrict__ row_tail) {
+    constexpr int NC = EPT / 8;
+    __shared__ float red[2][4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nchunk = d >> 3;
     const uint4* xr = reinterpret_cast<const uint4*>(x + (size_t)row * d);
-    float v[MAXC][8];
+    const uint4* wr = reinterpret_cast<const uint4*>(w);
+    float v[NC][8];
+    uint4 wu[NC];
     float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-        const int c = lane + i * 64;
+    for (int i = 0; i < NC; ++i) {
+        const int c = tid + i * 256;
         if (c < nchunk) {
             const uint4 u = xr[c];
+            wu[i] = wr[c];                              // requested with x: one memory phase, not two
             const bf16_t* p = reinterpret_cast<const bf16_t*>(&u);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -121,19 +128,21 @@ __global__ __launch_bounds__(256) void rmsnorm_quant_fp8_kernel(const bf16_t* __
             }
         }
     }
+    // the fp32 sum of the bf16-rounded squares: lanes, then waves, in a fixed order
     ss = wave_sum(ss);
+    if (lane == 0) red[0][wave] = ss;
+    __syncthreads();
+    ss = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
     const float ms = rbf(ss / (float)d);
     const float t = rbf(ms + eps);
     const bool tail = row_tail != nullptr && row_tail[row] != 0;
     const float r = tail ? rbf(1.0f / rbf(sqrtf(t))) : rbf(1.0f / sqrtf(t));
-    const uint4* wr = reinterpret_cast<const uint4*>(w);
     float amax = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-        const int c = lane + i * 64;
+    for (int i = 0; i < NC; ++i) {
+        const int c = tid + i * 256;
         if (c < nchunk) {
-            const uint4 wu = wr[c];
-            const bf16_t* wp = reinterpret_cast<const bf16_t*>(&wu);
+            const bf16_t* wp = reinterpret_cast<const bf16_t*>(&wu[i]);
             uint4 o;
             bf16_t* op = reinterpret_cast<bf16_t*>(&o);
 #pragma unroll
@@ -145,13 +154,16 @@ __global__ __launch_bounds__(256) void rmsnorm_quant_fp8_kernel(const bf16_t* __
             if (xn_out) reinterpret_cast<uint4*>(xn_out + (size_t)row * d)[c] = o;
         }
     }
-    amax = fmaxf(wave_max(amax), 1e-12f);
+    amax = wave_max(amax);
+    if (lane == 0) red[1][wave] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3])), 1e-12f);
     const float inv = __fdiv_rn(FP8_MAX, amax);
-    if (lane == 0) scale[row] = amax * INV_FP8_MAX;
+    if (tid == 0) scale[row] = amax * INV_FP8_MAX;
     uint2* qr = reinterpret_cast<uint2*>(q + (size_t)row * d);
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) {
-        const int c = lane + i * 64;
+    for (int i = 0; i < NC; ++i) {
+        const int c = tid + i * 256;
         if (c < nchunk)
             qr[c] = make_uint2(pack4_fp8(v[i][0] * inv, v[i][1] * inv, v[i][2] * inv, v[i][3] * inv),
                                pack4_fp8(v[i][4] * inv, v[i][5] * inv, v[i][6] * inv, v[i][7] * inv));
@@ -485,14 +497,10 @@ extern "C" int dh_rmsnorm_quant_fp8(const dh_bf16* x, const dh_bf16* w, dh_bf16*
     DH_CHECK(x && w && q && scale, "dh_rmsnorm_quant_fp8: null argument");
     DH_CHECK(rows >= 0 && d > 0 && d % 8 == 0 && d <= 8192, "dh_rmsnorm_quant_fp8: unsupported d=%d (need d %% 8 == 0, d <= 8192)", d);
     if (rows == 0) return 0;
-    dim3 grid(cdiv(rows, 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
-#define LAUNCH(MAXC) hipLaunchKernelGGL((rmsnorm_quant_fp8_kernel<MAXC>), grid, block, 0, s, x, w, xn_out, q, scale, rows, d, eps, row_tail)
-    if (d <= 512) { LAUNCH(1); }
-    else if (d <= 2048) { LAUNCH(4); }
-    else if (d <= 4096) { LAUNCH(8); }
-    else { LAUNCH(16); }
-#undef LAUNCH
+    if (d <= 2048) hipLaunchKernelGGL((rmsnorm_quant_fp8_block_kernel<8>), dim3(rows), dim3(256), 0, s, x, w, xn_out, q, scale, d, eps, row_tail);
+    else if (d <= 4096) hipLaunchKernelGGL((rmsnorm_quant_fp8_block_kernel<16>), dim3(rows), dim3(256), 0, s, x, w, xn_out, q, scale, d, eps, row_tail);
+    else hipLaunchKernelGGL((rmsnorm_quant_fp8_block_kernel<32>), dim3(rows), dim3(256), 0, s, x, w, xn_out, q, scale, d, eps, row_tail);
     DH_LAUNCH_CHECK();
     return 0;
 }

@@ -35,12 +35,20 @@ def test_row_quantisation_is_the_oracles():
         assert torch.equal(qw.cpu(), q_ref.view(torch.uint8)) and torch.equal(sw.cpu(), s_ref.view(-1))
     # fused with RMSNorm
     d = 4096
-    x, w = U((37, d), 2.0, "nx"), (1 + U((d,), 0.25, "nw").float()).bfloat16()
-    xn, q, s = ops.rmsnorm_quant_fp8(x.to(DEV), w.to(DEV), 1e-5)
-    want = ops.rmsnorm(x.to(DEV), w.to(DEV), 1e-5)
-    assert torch.equal(xn, want)
-    q_ref, s_ref = O.quantize_rows_fp8(want.cpu())
-    assert torch.equal(q.cpu(), q_ref.view(torch.uint8)) and torch.equal(s.cpu(), s_ref.view(-1))
+    w = (1 + U((d,), 0.25, "nw").float()).bfloat16()
+    for rows in (37, 300):
+        xr = U((rows, d), 2.0, f"nx{rows}")
+        xn, q, s = ops.rmsnorm_quant_fp8(xr.to(DEV), w.to(DEV), 1e-5)
+        want = ops.rmsnorm(xr.to(DEV), w.to(DEV), 1e-5)            # the bf16 kernel: same rounding points, another summation order
+        u = ulp_diff(xn.float().cpu(), want.float().cpu(), 1.0)
+        assert u.max().item() <= 1 and (u > 0).float().mean().item() <= 0.002
+        q_ref, s_ref = O.quantize_rows_fp8(xn.cpu())               # quantisation of the row the kernel itself produced
+        assert torch.equal(q.cpu(), q_ref.view(torch.uint8)) and torch.equal(s.cpu(), s_ref.view(-1))
+    # a row's result does not depend on how many rows ride along
+    xa = U((300, d), 2.0, "nx300").to(DEV)
+    one = ops.rmsnorm_quant_fp8(xa[7:8].contiguous(), w.to(DEV), 1e-5)
+    many = ops.rmsnorm_quant_fp8(xa, w.to(DEV), 1e-5)
+    assert torch.equal(one[0][0], many[0][7]) and torch.equal(one[1][0], many[1][7]) and torch.equal(one[2], many[2][7:8])
 
 
 @pytest.mark.parametrize("M", [1, 19, 32, 33, 200])
