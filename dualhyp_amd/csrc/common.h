@@ -47,6 +47,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// the same with the non-temporal policy (aux = 2): bytes this CU alone reads once (streamed weights)
+__device__ __forceinline__ void glds16_nt(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2);
+}
+
 // ---- KV cache in MFMA-fragment order --------------------------------------------------------
 // Both caches are stored per (slot, group) as 32-key tiles of HS*32 elements, laid out so that a
 // wave-wide contiguous 1-KiB load (lane i <- 16 B at i*16) IS an MFMA operand fragment:

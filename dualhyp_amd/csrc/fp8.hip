@@ -11,7 +11,7 @@
 //   rmsnorm_quant_fp8_block_kernel  RMSNorm (ger/rmsnorm.py:17-21, bf16 rounding points) with the quantisation fused
 //   gemm_fp8_kernel             M > 32: 128 x 128 x 128 tiles, both operands through LDS (global_load_lds 16 B, rows
 //                               of 128 B with the source-side XOR swizzle of gemm.hip), 4 waves x (4 x 4) MFMA tiles
-//   gemm_fp8_skinny_kernel      M <= 32 (decode): W streamed HBM -> VGPR once, K dealt over the 8 waves of a block
+//   gemm_fp8_skinny_kernel      M <= 128 (decode, up to four 32-row batches): W streamed HBM -> VGPR once, K dealt over the 8 waves of a block
 // Tried and dropped: a port of gemm256.hip's 256 x 256 ping-pong kernel to v_mfma_scale_f32_32x32x64_f8f6f4 (operand map
 // verified with integers: lane l = row l & 31, k 32 (l >> 5) ..+32).  With two fragment sets it spills (128 accumulator
 // + 2 x 48 fragment registers: 0.57 PFLOP/s), with one set it reaches 1.15 PFLOP/s against 1.5 for the 128-tile kernel.
@@ -362,9 +362,12 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(Fp8Args a) {
 // 128-wide k-steps over the 8 waves, W global -> VGPR (non-temporal, each byte is needed once), the per-wave fp32
 // partials meet in LDS and thread t finishes output (n = t & 15, m = t >> 4).
 constexpr int ROWS = 16, NW = 8;
+constexpr int FP8_STREAM_MAX_ROWS = 128;
 
-template <int EPI, bool RESID, bool OUT32 = false>
+template <int EPI, bool RESID, bool OUT32 = false, int NG = 1>
 __global__ __launch_bounds__(512, 2) void gemm_fp8_skinny_kernel(Fp8Args a) {
+    // NG 32-row groups (several batches decoded in one step) reuse the W fragments a wave holds: W is still streamed
+    // once.  A row's chain (its wave's k-steps ascending, waves added in order) is the same for every NG.
     constexpr bool SW = EPI == DH_EPI_SWIGLU;
     constexpr int CH = SW ? 2 : 4;                        // k-steps (32 B per lane and operand) loaded ahead per wave
     __shared__ __attribute__((aligned(16))) float part[NW][32][ROWS];
@@ -376,11 +379,16 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_skinny_kernel(Fp8Args a) {
     n = n < a.N ? n : a.N - 1;
     const uint8_t* wrow = a.w + (size_t)n * a.K + kg * 32;
     const uint8_t* wrow2 = SW ? a.w2 + (size_t)n * a.K + kg * 32 : nullptr;
-    int m_lo = lrow, m_hi = 16 + lrow;
-    m_lo = m_lo < a.M ? m_lo : a.M - 1;
-    m_hi = m_hi < a.M ? m_hi : a.M - 1;
-    const uint8_t* xlo = a.x + (size_t)m_lo * a.K + kg * 32;
-    const uint8_t* xhi = a.x + (size_t)m_hi * a.K + kg * 32;
+    const uint8_t* xlo[NG];
+    const uint8_t* xhi[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        int m_lo = g * 32 + lrow, m_hi = g * 32 + 16 + lrow;
+        m_lo = m_lo < a.M ? m_lo : a.M - 1;
+        m_hi = m_hi < a.M ? m_hi : a.M - 1;
+        xlo[g] = a.x + (size_t)m_lo * a.K + kg * 32;
+        xhi[g] = a.x + (size_t)m_hi * a.K + kg * 32;
+    }
     auto ldw = [](const uint8_t* p) __attribute__((always_inline)) -> i32x8 {
         const i32x4 lo = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(p));
         const i32x4 hi = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(p + 16));
@@ -391,67 +399,88 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_skinny_kernel(Fp8Args a) {
         const uint4 hi = *reinterpret_cast<const uint4*>(p + 16);
         return i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
     };
-    f32x4 acc_lo = {0.f, 0.f, 0.f, 0.f}, acc_hi = {0.f, 0.f, 0.f, 0.f};
-    f32x4 acc2_lo = {0.f, 0.f, 0.f, 0.f}, acc2_hi = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc_lo[NG], acc_hi[NG], acc2_lo[SW ? NG : 1], acc2_hi[SW ? NG : 1];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        acc_lo[g] = acc_hi[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (SW) acc2_lo[g] = acc2_hi[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     const int nks = a.K / 128;
     for (int ks0 = wave; ks0 < nks; ks0 += NW * CH) {
-        i32x8 wf[CH], wf2[CH], xl[CH], xh[CH];
+        i32x8 wf[CH], wf2[SW ? CH : 1];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const int ks = ks0 + c * NW;
             if (ks < nks) {
                 wf[c] = ldw(wrow + (size_t)ks * 128);
                 if (SW) wf2[c] = ldw(wrow2 + (size_t)ks * 128);
-                xl[c] = ldx(xlo + (size_t)ks * 128);
-                xh[c] = ldx(xhi + (size_t)ks * 128);
             }
         }
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            const int ks = ks0 + c * NW;
-            if (ks < nks) {
-                acc_lo = mfma_fp8(wf[c], xl[c], acc_lo);
-                acc_hi = mfma_fp8(wf[c], xh[c], acc_hi);
-                if (SW) {
-                    acc2_lo = mfma_fp8(wf2[c], xl[c], acc2_lo);
-                    acc2_hi = mfma_fp8(wf2[c], xh[c], acc2_hi);
+        for (int g = 0; g < NG; ++g) {
+            if (g * 32 >= a.M) break;
+            i32x8 xl[CH], xh[CH];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int ks = ks0 + c * NW;
+                if (ks < nks) {
+                    xl[c] = ldx(xlo[g] + (size_t)ks * 128);
+                    xh[c] = ldx(xhi[g] + (size_t)ks * 128);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int ks = ks0 + c * NW;
+                if (ks < nks) {
+                    acc_lo[g] = mfma_fp8(wf[c], xl[c], acc_lo[g]);
+                    acc_hi[g] = mfma_fp8(wf[c], xh[c], acc_hi[g]);
+                    if (SW) {
+                        acc2_lo[g] = mfma_fp8(wf2[c], xl[c], acc2_lo[g]);
+                        acc2_hi[g] = mfma_fp8(wf2[c], xh[c], acc2_hi[g]);
+                    }
                 }
             }
         }
     }
-    // C layout: col (m) = lane & 15, rows (n) = 4*(lane>>4) + reg
-    *reinterpret_cast<f32x4*>(&part[wave][lrow][kg * 4]) = acc_lo;
-    *reinterpret_cast<f32x4*>(&part[wave][16 + lrow][kg * 4]) = acc_hi;
-    if (SW) {
-        *reinterpret_cast<f32x4*>(&part2[wave][lrow][kg * 4]) = acc2_lo;
-        *reinterpret_cast<f32x4*>(&part2[wave][16 + lrow][kg * 4]) = acc2_hi;
-    }
-    __syncthreads();
-    const int tn = tid & 15, tm = tid >> 4, nn = n0 + tn;
-    if (tm >= a.M || nn >= a.N) return;
-    const float* p = &part[0][0][0] + tm * ROWS + tn;
-    const float xs = a.xs[tm];
-    float o;
-    if (SW) {
-        float g = 0.f, u = 0.f;
-        const float* p2 = &part2[0][0][0] + tm * ROWS + tn;
+    const int tn = tid & 15, tmi = tid >> 4, nn = n0 + tn;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) {
-            g += p[w * 32 * ROWS];
-            u += p2[w * 32 * ROWS];
+    for (int g = 0; g < NG; ++g) {
+        if (g * 32 >= a.M) break;                          // block-uniform
+        if (g > 0) __syncthreads();                        // the previous group's sums have been read
+        // C layout: col (m) = lane & 15, rows (n) = 4*(lane>>4) + reg
+        *reinterpret_cast<f32x4*>(&part[wave][lrow][kg * 4]) = acc_lo[g];
+        *reinterpret_cast<f32x4*>(&part[wave][16 + lrow][kg * 4]) = acc_hi[g];
+        if (SW) {
+            *reinterpret_cast<f32x4*>(&part2[wave][lrow][kg * 4]) = acc2_lo[g];
+            *reinterpret_cast<f32x4*>(&part2[wave][16 + lrow][kg * 4]) = acc2_hi[g];
         }
-        g = rbf(g * (xs * a.ws[nn]));
-        u = rbf(u * (xs * a.ws2[nn]));
-        o = rbf(g / (1.0f + expf(-g))) * u;
-    } else {
-        float s = 0.f;
+        __syncthreads();
+        const int tm = g * 32 + tmi;
+        if (tm >= a.M || nn >= a.N) continue;
+        const float* p = &part[0][0][0] + tmi * ROWS + tn;
+        const float xs = a.xs[tm];
+        float o;
+        if (SW) {
+            float gt = 0.f, u = 0.f;
+            const float* p2 = &part2[0][0][0] + tmi * ROWS + tn;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) s += p[w * 32 * ROWS];
-        o = fp8_finish<EPI>(s, xs * a.ws[nn], a, nn);
-        if (RESID) o = bf2f(a.resid[(size_t)tm * a.N + nn]) + o;
+            for (int w = 0; w < NW; ++w) {
+                gt += p[w * 32 * ROWS];
+                u += p2[w * 32 * ROWS];
+            }
+            gt = rbf(gt * (xs * a.ws[nn]));
+            u = rbf(u * (xs * a.ws2[nn]));
+            o = rbf(gt / (1.0f + expf(-gt))) * u;
+        } else {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s += p[w * 32 * ROWS];
+            o = fp8_finish<EPI>(s, xs * a.ws[nn], a, nn);
+            if (RESID) o = bf2f(a.resid[(size_t)tm * a.N + nn]) + o;
+        }
+        if (OUT32) reinterpret_cast<float*>(a.y)[(size_t)tm * a.N + nn] = o;     // bf16-exact value as fp32 (fused decode consumer)
+        else a.y[(size_t)tm * a.N + nn] = f2bf(o);
     }
-    if (OUT32) reinterpret_cast<float*>(a.y)[(size_t)tm * a.N + nn] = o;     // bf16-exact value as fp32 (fused decode consumer)
-    else a.y[(size_t)tm * a.N + nn] = f2bf(o);
 }
 
 template <int EPI, bool RESID, int NST>
@@ -470,13 +499,20 @@ int launch_tiled(const Fp8Args& a, hipStream_t s) {
     return a.resid ? launch_tiled_n<EPI, true, 2>(a, s) : launch_tiled_n<EPI, false, 2>(a, s);
 }
 
-template <int EPI>
-int launch_skinny(const Fp8Args& a, hipStream_t s) {
+template <int EPI, int NG>
+int launch_skinny_ng(const Fp8Args& a, hipStream_t s) {
     dim3 grid(cdiv(a.N, ROWS)), block(512);
-    if (a.resid) hipLaunchKernelGGL((gemm_fp8_skinny_kernel<EPI, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((gemm_fp8_skinny_kernel<EPI, false>), grid, block, 0, s, a);
+    if (a.resid) hipLaunchKernelGGL((gemm_fp8_skinny_kernel<EPI, true, false, NG>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gemm_fp8_skinny_kernel<EPI, false, false, NG>), grid, block, 0, s, a);
     DH_LAUNCH_CHECK();
     return 0;
+}
+
+template <int EPI>
+int launch_skinny(const Fp8Args& a, hipStream_t s) {
+    if (a.M <= 32) return launch_skinny_ng<EPI, 1>(a, s);
+    if (a.M <= 64) return launch_skinny_ng<EPI, 2>(a, s);
+    return launch_skinny_ng<EPI, 4>(a, s);
 }
 
 }  // namespace
@@ -527,7 +563,7 @@ extern "C" int dh_linear_fp8(const uint8_t* xq, const float* x_scale, const uint
     if (M == 0) return 0;
     Fp8Args a{xq, wq, w2q, y, x_scale, w_scale, w2_scale, vec_a, vec_b, resid, M, N, K, 0, 0};
     hipStream_t s = (hipStream_t)stream;
-    if (M <= 32) {
+    if (M <= FP8_STREAM_MAX_ROWS) {      // weight streaming: the decode step of up to four 32-row batches
         switch (epilogue) {
             case DH_EPI_PLAIN: return launch_skinny<DH_EPI_PLAIN>(a, s);
             case DH_EPI_SWIGLU: return launch_skinny<DH_EPI_SWIGLU>(a, s);

@@ -21,6 +21,19 @@
 #include "common.h"
 #include "gemm.h"
 
+#ifdef DH_MID_STAMPS   // diagnostic build only (tools/probe_mid.py): 100 MHz timestamps of wave 0 / wave 8 per block
+__device__ unsigned long long g_mid_stamps[1024 * 8];
+#define MID_STAMP(i) do { if (lane == 0 && (wave == 0 || wave == 8) && blockIdx.y == 0 && blockIdx.x < 1024) \
+    g_mid_stamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int dh_debug_mid_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mid_stamps), sizeof(g_mid_stamps)) == hipSuccess ? 0 : 1;
+}
+#else
+#define MID_STAMP(i)
+#endif
+
+int g_mid_wlds = 1;   // 1: W through the per-wave LDS ring (<= 64 rows), 0: W straight to VGPRs (dh_set_tuning 13)
+
 namespace {
 
 constexpr int KSL = 4;             // k-steps (of 32) per slice
@@ -39,12 +52,21 @@ struct MidShape {
 // W slices held per wave (RING-1 in flight + the one being multiplied); 170 VGPRs per wave at 10 waves
 template <int EPI, int NG> constexpr int mid_ring() { return 8; }
 
-template <int EPI, int NG>
+// WL: the W stream goes global -> LDS (LDS-DMA, full 128-B lines: 8 rows x 2 k-steps per request) into a ring private
+// to the wave, and reaches the MFMA through ds_read_b128; otherwise global -> VGPR in fragment shape (16 rows x 64 B
+// per request), which costs the texture-address unit four times the line look-ups per byte and bounds the kernel.
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int NG> constexpr int wl_ring_bytes() { return NG == 1 ? 16384 : 12288; }   // per wave
+
+template <int EPI, int NG, bool WL>
 __global__ __launch_bounds__(640) void gemm_mid_kernel(GemmArgs a) {
     using S = MidShape<EPI>;
     constexpr bool SW = S::SW;
     constexpr int NM = S::NM, KQ = S::KQ, RS = S::RS, KPW = S::KPW;
     constexpr int RING = mid_ring<EPI, NG>(), PD = RING - 1;
+    constexpr int CI = NM * 2;                            // WL: LDS-DMA requests per chunk (= 2 k-steps): [matrix][row half], 1 KiB each
+    constexpr int CB = CI * 1024;                         // bytes per chunk
+    constexpr int RC = wl_ring_bytes<NG>() / CB;          // chunks in a wave's ring
     constexpr int NI = NG * NM * 2;                       // accumulator tiles per wave
     constexpr int NXL = NG * 4;                           // x requests per loader wave per slice (4 rows each)
     constexpr int XBUF = NG * 32 * XROW;                  // bytes per x buffer
@@ -53,6 +75,7 @@ __global__ __launch_bounds__(640) void gemm_mid_kernel(GemmArgs a) {
     const int m0 = blockIdx.y * (NG * 32);
     const int nsl = a.K / (KSL * 32);                     // K % 128 == 0 (checked on the host)
     const int kpart = a.K / 32 / KQ;                      // k-steps per K-part: part q owns k-steps [q*kpart, (q+1)*kpart)
+    MID_STAMP(wave == 0 ? 0 : 4);
 
     if (wave >= 8) {
         // ---- loader waves: x slices global -> LDS, XD slices ahead of the MFMAs.  vmcnt is an in-order
@@ -78,6 +101,7 @@ __global__ __launch_bounds__(640) void gemm_mid_kernel(GemmArgs a) {
 #pragma unroll
         for (int p = 0; p < XD; ++p) load_x(p);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((XD - 1) * NXL) : "memory");   // slice 0 has landed
+        MID_STAMP(5);
         __builtin_amdgcn_s_barrier();
         for (int s = 0; s < nsl; ++s) {
             load_x(s + XD);            // buffer (s+XD) % NBUF was last read in step s-1, which ended with a barrier
@@ -95,54 +119,147 @@ __global__ __launch_bounds__(640) void gemm_mid_kernel(GemmArgs a) {
     const int n0 = blockIdx.x * (16 * RS) + rs * 16;
     int n = n0 + lrow;
     n = n < a.N ? n : a.N - 1;
+#if defined(DH_MID_WSHAPE) && DH_MID_WSHAPE == 1      // timing experiment (wrong results): same bytes per instruction, lane-sorted
+    const int nx = min(n0 + (lane >> 2), a.N - 1);
+    const bf16_t* w1 = a.w + (size_t)nx * a.K + (lane & 3) * 8;
+    const bf16_t* w2 = SW ? a.w2 + (size_t)nx * a.K + (lane & 3) * 8 : nullptr;
+#elif defined(DH_MID_WSHAPE) && DH_MID_WSHAPE == 2    // timing experiment (wrong results): 8 rows x 128 B per instruction
+    const int nx = min(n0 + (lane >> 3), a.N - 1);
+    const bf16_t* w1 = a.w + (size_t)nx * a.K + (lane & 7) * 8;
+    const bf16_t* w2 = SW ? a.w2 + (size_t)nx * a.K + (lane & 7) * 8 : nullptr;
+#else
     const bf16_t* w1 = a.w + (size_t)n * a.K + kg * 8;
     const bf16_t* w2 = SW ? a.w2 + (size_t)n * a.K + kg * 8 : nullptr;
+#endif
 
     f32x4 acc[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 wr[RING][NM][KPW];
-    auto load_w = [&](bf16x8 (&wf)[NM][KPW], int s) __attribute__((always_inline)) {
+    if constexpr (WL) {
+        // ---- W: chunk j = k-steps 2j, 2j+1 of this wave's K-part, NM matrices x 16 rows x 128 B.  Request (q, h) moves
+        // rows 8h..8h+7 of matrix q as full lines: lane -> (row lane/8, 16-B piece (lane%8) ^ row) so that the image
+        // [8 rows][128 B] is read back conflict free (fragment of k-step t: piece (4t + kg) ^ row).  The ring is private:
+        // only this wave's own counted vmcnt orders it, no barrier.
+        char* wring = smem + NBUF * XBUF + wave * (RC * CB);
+        const int nch = kpart >> 1;                        // K % (64 * KQ) == 0 (checked on the host)
+        const int wr8 = lane >> 3;
+        const bf16_t* wsrc[CI];
 #pragma unroll
-        for (int c = 0; c < KPW; ++c) {
-            const int ko = (kq * kpart + s * KPW + c) * 32;
-            wf[0][c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(w1 + ko));
-            if (SW) wf[NM - 1][c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(w2 + ko));
+        for (int q = 0; q < NM; ++q)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                int nr = n0 + h * 8 + wr8;
+                nr = nr < a.N ? nr : a.N - 1;
+                wsrc[q * 2 + h] = (q == 0 ? a.w : a.w2) + (size_t)nr * a.K + (size_t)kq * kpart * 32 + (((lane & 7) ^ wr8) << 3);
+            }
+        auto issue = [&](int j) __attribute__((always_inline)) {
+            char* dst = wring + (j % RC) * CB;
+#pragma unroll
+            for (int i = 0; i < CI; ++i) glds16_nt(wsrc[i] + j * 64, dst + i * 1024);
+        };
+        int foff[2];                                       // this lane's fragment within a matrix image pair, k-step t
+#pragma unroll
+        for (int t = 0; t < 2; ++t) foff[t] = (lrow >> 3) * 1024 + (lrow & 7) * 128 + (((t * 4 + kg) ^ (lrow & 7)) << 4);
+#pragma unroll
+        for (int j = 0; j < RC; ++j)
+            if (j < nch) issue(j);
+        MID_STAMP(1);
+        __builtin_amdgcn_s_barrier();      // x slice 0
+        MID_STAMP(2);
+        for (int s = 0; s < nsl; ++s) {
+            const char* xb = smem + (s % NBUF) * XBUF;
+#pragma unroll
+            for (int c = 0; c < KPW; ++c) {
+                const int kk = s * KPW + c, j = kk >> 1, t = kk & 1;
+                if (t == 0) {              // chunk j has landed once at most min(nch - j, RC) - 1 younger chunks are outstanding
+                    const int rem = (nch - j < RC ? nch - j : RC) - 1;
+                    switch (rem) {
+                        case 0: wait_vm<0>(); break;
+                        case 1: wait_vm<CI>(); break;
+                        case 2: wait_vm<(RC > 2 ? 2 : 1) * CI>(); break;
+                        case 3: wait_vm<(RC > 3 ? 3 : 1) * CI>(); break;
+                        case 4: wait_vm<(RC > 4 ? 4 : 1) * CI>(); break;
+                        case 5: wait_vm<(RC > 5 ? 5 : 1) * CI>(); break;
+                        case 6: wait_vm<(RC > 6 ? 6 : 1) * CI>(); break;
+                        default: wait_vm<(RC - 1) * CI>(); break;
+                    }
+                }
+                const char* wb = wring + (j % RC) * CB + foff[t];
+                bf16x8 wf[NM];
+#pragma unroll
+                for (int q = 0; q < NM; ++q) wf[q] = *reinterpret_cast<const bf16x8*>(wb + q * 2048);
+                const int ch = (kq * KPW + c) * 4 + kg;            // logical 16-B chunk of the x row
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if (m0 + g * 32 < a.M) {
+                        const bf16x8 xl = *reinterpret_cast<const bf16x8*>(xb + (g * 32 + lrow) * XROW + ((ch ^ lrow) << 4));
+                        const bf16x8 xh = *reinterpret_cast<const bf16x8*>(xb + (g * 32 + 16 + lrow) * XROW + ((ch ^ lrow) << 4));
+#pragma unroll
+                        for (int q = 0; q < NM; ++q) {
+                            acc[(g * NM + q) * 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[q], xl, acc[(g * NM + q) * 2], 0, 0, 0);
+                            acc[(g * NM + q) * 2 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[q], xh, acc[(g * NM + q) * 2 + 1], 0, 0, 0);
+                        }
+                    }
+                }
+                if (t == 1 && j + RC < nch) {              // the chunk's fragments are in registers: refill its slot
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    issue(j + RC);
+                }
+            }
+            __builtin_amdgcn_s_barrier();      // the loader waves arrive here once slice s+1 is in LDS
         }
-    };
-    auto body = [&](bf16x8 (&cur)[NM][KPW], bf16x8 (&ahead)[NM][KPW], int s) __attribute__((always_inline)) {
-        if (s + PD < nsl) load_w(ahead, s + PD);
-        const char* xb = smem + (s % NBUF) * XBUF;
+        __builtin_amdgcn_s_barrier();          // every x read done, loader tail requests landed
+        MID_STAMP(3);
+    } else {
+    bf16x8 wr[RING][NM][KPW];
+        auto load_w = [&](bf16x8 (&wf)[NM][KPW], int s) __attribute__((always_inline)) {
 #pragma unroll
-        for (int c = 0; c < KPW; ++c) {
-            const int ch = (kq * KPW + c) * 4 + kg;            // logical 16-B chunk of the row
+            for (int c = 0; c < KPW; ++c) {
+#if defined(DH_MID_WSHAPE) && DH_MID_WSHAPE == 2
+                const int ko = (kq * kpart + ((s * KPW + c) & ~1)) * 32 + ((s * KPW + c) & 1) * 8 * a.K;
+#else
+                const int ko = (kq * kpart + s * KPW + c) * 32;
+#endif
+                wf[0][c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(w1 + ko));
+                if (SW) wf[NM - 1][c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(w2 + ko));
+            }
+        };
+        auto body = [&](bf16x8 (&cur)[NM][KPW], bf16x8 (&ahead)[NM][KPW], int s) __attribute__((always_inline)) {
+            if (s + PD < nsl) load_w(ahead, s + PD);
+            const char* xb = smem + (s % NBUF) * XBUF;
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                if (m0 + g * 32 < a.M) {
-                    const bf16x8 xl = *reinterpret_cast<const bf16x8*>(xb + (g * 32 + lrow) * XROW + ((ch ^ lrow) << 4));
-                    const bf16x8 xh = *reinterpret_cast<const bf16x8*>(xb + (g * 32 + 16 + lrow) * XROW + ((ch ^ lrow) << 4));
+            for (int c = 0; c < KPW; ++c) {
+                const int ch = (kq * KPW + c) * 4 + kg;            // logical 16-B chunk of the row
 #pragma unroll
-                    for (int q = 0; q < NM; ++q) {
-                        acc[(g * NM + q) * 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[q][c], xl, acc[(g * NM + q) * 2], 0, 0, 0);
-                        acc[(g * NM + q) * 2 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[q][c], xh, acc[(g * NM + q) * 2 + 1], 0, 0, 0);
+                for (int g = 0; g < NG; ++g) {
+                    if (m0 + g * 32 < a.M) {
+                        const bf16x8 xl = *reinterpret_cast<const bf16x8*>(xb + (g * 32 + lrow) * XROW + ((ch ^ lrow) << 4));
+                        const bf16x8 xh = *reinterpret_cast<const bf16x8*>(xb + (g * 32 + 16 + lrow) * XROW + ((ch ^ lrow) << 4));
+#pragma unroll
+                        for (int q = 0; q < NM; ++q) {
+                            acc[(g * NM + q) * 2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[q][c], xl, acc[(g * NM + q) * 2], 0, 0, 0);
+                            acc[(g * NM + q) * 2 + 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[q][c], xh, acc[(g * NM + q) * 2 + 1], 0, 0, 0);
+                        }
                     }
                 }
             }
+            __builtin_amdgcn_s_barrier();      // the loader waves arrive here once slice s+1 is in LDS
+        };
+
+#pragma unroll
+        for (int p = 0; p < PD; ++p)
+            if (p < nsl) load_w(wr[p], p);
+        MID_STAMP(1);
+        __builtin_amdgcn_s_barrier();          // x slice 0
+        MID_STAMP(2);
+        for (int s0 = 0; s0 < nsl; s0 += RING) {
+#pragma unroll
+            for (int r = 0; r < RING; ++r)
+                if (s0 + r < nsl) body(wr[r], wr[(r + PD) % RING], s0 + r);
         }
-        __builtin_amdgcn_s_barrier();      // the loader waves arrive here once slice s+1 is in LDS
-    };
-
-#pragma unroll
-    for (int p = 0; p < PD; ++p)
-        if (p < nsl) load_w(wr[p], p);
-    __builtin_amdgcn_s_barrier();          // x slice 0
-    for (int s0 = 0; s0 < nsl; s0 += RING) {
-#pragma unroll
-        for (int r = 0; r < RING; ++r)
-            if (s0 + r < nsl) body(wr[r], wr[(r + PD) % RING], s0 + r);
+        __builtin_amdgcn_s_barrier();          // every x read done, loader tail requests landed
+        MID_STAMP(3);
     }
-    __builtin_amdgcn_s_barrier();          // every x read done, loader tail requests landed
-
     // ---- the KQ partial tiles of a row set meet in LDS (every x buffer read ended at the last barrier).
     // Output tile pair t = (g, h) is finished by K-part t % KQ: every wave parks the tiles it does not
     // own, then sums its own in K-part order 0..KQ-1 (its register value taking its place in that order).
@@ -204,14 +321,24 @@ __global__ __launch_bounds__(640) void gemm_mid_kernel(GemmArgs a) {
         const uint2 pk = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
         *reinterpret_cast<uint2*>(a.y + (size_t)m * a.N + nn) = pk;
     }
+    MID_STAMP(6);
 }
 
 template <int EPI, int NG>
 int launch_mid(const GemmArgs& a, hipStream_t s) {
-    constexpr int lds = NBUF * NG * 32 * XROW;
-    if (lds > 48 * 1024) DH_MAX_LDS_ONCE((gemm_mid_kernel<EPI, NG>), lds);
+    constexpr int xlds = NBUF * NG * 32 * XROW;
     dim3 grid(cdiv(a.N, 16 * MidShape<EPI>::RS), cdiv(a.M, NG * 32)), block(640);
-    hipLaunchKernelGGL((gemm_mid_kernel<EPI, NG>), grid, block, lds, s, a);
+    if constexpr (NG <= 2) {
+        if (g_mid_wlds && a.K % (64 * MidShape<EPI>::KQ) == 0) {
+            constexpr int lds = xlds + 8 * wl_ring_bytes<NG>();
+            DH_MAX_LDS_ONCE((gemm_mid_kernel<EPI, NG, true>), lds);
+            hipLaunchKernelGGL((gemm_mid_kernel<EPI, NG, true>), grid, block, lds, s, a);
+            DH_LAUNCH_CHECK();
+            return 0;
+        }
+    }
+    if (xlds > 48 * 1024) DH_MAX_LDS_ONCE((gemm_mid_kernel<EPI, NG, false>), xlds);
+    hipLaunchKernelGGL((gemm_mid_kernel<EPI, NG, false>), grid, block, xlds, s, a);
     DH_LAUNCH_CHECK();
     return 0;
 }

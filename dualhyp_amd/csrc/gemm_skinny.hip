@@ -453,6 +453,7 @@ extern "C" int dh_set_tuning(int key, int value) {
     if (key == 10 && value >= 0) { extern int g_decode_tiled_rows; g_decode_tiled_rows = value; return 0; }
     if (key == 11 && value >= 0) { g_rows_ct = value; return 0; }
     if (key == 12) { extern int g_fuse_qkv_rope; g_fuse_qkv_rope = value; return 0; }
+    if (key == 13) { extern int g_mid_wlds; g_mid_wlds = value; return 0; }
     dh_set_error("dh_set_tuning: unknown key %d", key);
     return 1;
 }

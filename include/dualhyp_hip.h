@@ -247,7 +247,7 @@ int dh_rmsnorm_quant_fp8(const dh_bf16* x, const dh_bf16* w, dh_bf16* xn_out, ui
                          float eps, const uint8_t* row_tail, void* stream);
 /* y[M,N] bf16 = epilogue( bf16( (xq . wq^T in fp32) * (x_scale[m] * w_scale[n]) ) ) on the block-scaled fp8 MFMA
  * (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales).  K %% 128 == 0, N %% 4 == 0.  Epilogues: DH_EPI_PLAIN
- * (+ resid), DH_EPI_SWIGLU (w2q / w2_scale = fc_2), DH_EPI_ADAPTER (vec_a scale, vec_b bias).  M <= 32 streams the
+ * (+ resid), DH_EPI_SWIGLU (w2q / w2_scale = fc_2), DH_EPI_ADAPTER (vec_a scale, vec_b bias).  M <= 128 streams the
  * weights once (decode), larger M runs 128 x 128 x 128 tiles. */
 int dh_linear_fp8(const uint8_t* xq, const float* x_scale, const uint8_t* wq, const float* w_scale, dh_bf16* y, int M, int N,
                   int K, int epilogue, const uint8_t* w2q, const float* w2_scale, const dh_bf16* vec_a, const dh_bf16* vec_b,
