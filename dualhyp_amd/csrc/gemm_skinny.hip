@@ -277,7 +277,6 @@ __global__ __launch_bounds__(512, NG == 1 ? 2 : 1) void gemm_skinny_rows_kernel(
                                                                               const bf16_t* __restrict__ w_ext,
                                                                               float* __restrict__ y32, int M, int n_main,
                                                                               int N, int K) {
-    static_assert(NG % NGL == 0, "LDS rounds must divide the row groups");
     constexpr int XS = KPS * 64 + 16;                      // padded row stride of the x slice (bytes)
     extern __shared__ __attribute__((aligned(16))) char sx[];   // [NGL*32][XS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -307,7 +306,7 @@ __global__ __launch_bounds__(512, NG == 1 ? 2 : 1) void gemm_skinny_rows_kernel(
         for (int i = 0; i < NGL * 32 * KPS * 4 / 512; ++i) {
             const int c = tid + i * 512;
             const int row = c / (KPS * 4), col = c % (KPS * 4);
-            if (col < ks_cnt * 4) {
+            if (col < ks_cnt * 4 && r0 * 32 + row < NG * 32) {     // (the last round may hold fewer than NGL groups)
                 int m = mr + row;
                 m = m < M ? m : M - 1;
                 *reinterpret_cast<uint4*>(sx + row * XS + col * 16) =
@@ -318,7 +317,7 @@ __global__ __launch_bounds__(512, NG == 1 ? 2 : 1) void gemm_skinny_rows_kernel(
 #pragma unroll
         for (int g = 0; g < NGL; ++g) {
             const int mg = mr + g * 32;
-            if (mg >= M) break;
+            if (mg >= M || r0 + g >= NG) break;
             f32x4 acc_lo[CT], acc_hi[CT];
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) acc_lo[ct] = acc_hi[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -347,13 +346,14 @@ __global__ __launch_bounds__(512, NG == 1 ? 2 : 1) void gemm_skinny_rows_kernel(
     }
 }
 
+int g_rows_ng = 0;   // 0: by grid size; 8 or 10 row groups per block above 128 rows (dh_set_tuning key 14)
 int g_rows_ct = 0;   // 0: by row count; else forced column tiles per wave (dh_set_tuning key 11: 1, 2 or 4)
 
 template <int KPS, int NG, int CT>
 int launch_rows(const bf16_t* x, const bf16_t* w, const bf16_t* w_ext, float* y32, int M, int n_main, int N, int K,
                 int ksplit, hipStream_t s) {
     constexpr int XS = KPS * 64 + 16;
-    constexpr int NGL = NG * 32 * XS <= 144 * 1024 ? NG : NG / 2;   // groups resident in LDS at once
+    constexpr int NGL = NG * 32 * XS <= 144 * 1024 ? NG : (NG / 2 * 32 * XS <= 144 * 1024 ? NG / 2 : 4);   // groups resident in LDS at once
     constexpr int lds = NGL * 32 * XS;
     static_assert(lds <= 160 * 1024, "x slice does not fit in LDS");
     if (lds > 48 * 1024) DH_MAX_LDS_ONCE((gemm_skinny_rows_kernel<KPS, NG, NGL, CT>), lds);
@@ -375,7 +375,17 @@ int launch_rows_ng(const bf16_t* x, const bf16_t* w, const bf16_t* w_ext, float*
     constexpr int CTMAX = KPS == 8 ? 4 : 2;               // W fragments: CT * KPS * 4 VGPRs
     const int ct = g_rows_ct ? g_rows_ct : 2;
     if (ct >= 4 && CTMAX >= 4) return launch_rows<KPS, 8, CTMAX>(x, w, w_ext, y32, M, n_main, N, K, ksplit, s);
-    if (ct >= 2) return launch_rows<KPS, 8, 2>(x, w, w_ext, y32, M, n_main, N, K, ksplit, s);
+    if (ct >= 2) {
+        // one block per CU: a grid just over 256 blocks (640 rows: 264) runs a second round for a handful of blocks.
+        // 10 row groups per block instead of 8 when that saves a round (block time ~ 5 + 2 us per group).
+        auto cost = [&](int ng) {
+            const int blocks = cdiv(N, 256) * ksplit * cdiv(M, ng * 32);
+            return cdiv(blocks, 256) * (5 + 2 * ng);
+        };
+        const bool ten = g_rows_ng ? g_rows_ng == 10 : cost(10) < cost(8);
+        if (ten) return launch_rows<KPS, 10, 2>(x, w, w_ext, y32, M, n_main, N, K, ksplit, s);
+        return launch_rows<KPS, 8, 2>(x, w, w_ext, y32, M, n_main, N, K, ksplit, s);
+    }
     return launch_rows<KPS, 8, 1>(x, w, w_ext, y32, M, n_main, N, K, ksplit, s);
 }
 
@@ -453,6 +463,7 @@ extern "C" int dh_set_tuning(int key, int value) {
     if (key == 10 && value >= 0) { extern int g_decode_tiled_rows; g_decode_tiled_rows = value; return 0; }
     if (key == 11 && value >= 0) { g_rows_ct = value; return 0; }
     if (key == 12) { extern int g_fuse_qkv_rope; g_fuse_qkv_rope = value; return 0; }
+    if (key == 14 && (value == 0 || value == 8 || value == 10)) { g_rows_ng = value; return 0; }
     if (key == 13) { extern int g_mid_wlds; g_mid_wlds = value; return 0; }
     dh_set_error("dh_set_tuning: unknown key %d", key);
     return 1;
