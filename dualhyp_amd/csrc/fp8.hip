@@ -375,30 +375,38 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_skinny_kernel(Fp8Args a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * ROWS;
     const int lrow = lane & 15, kg = lane >> 4;
-    int n = n0 + lrow;
-    n = n < a.N ? n : a.N - 1;
-    const uint8_t* wrow = a.w + (size_t)n * a.K + kg * 32;
-    const uint8_t* wrow2 = SW ? a.w2 + (size_t)n * a.K + kg * 32 : nullptr;
-    const uint8_t* xlo[NG];
-    const uint8_t* xhi[NG];
+    // Operands are fetched as FULL 128-B lines — request h covers rows 8h..8h+7 of a 16-row block, lane -> (row lane/8,
+    // 16-B piece lane%8) — and turned into MFMA fragments (lane (row, kg) holds pieces 2kg, 2kg+1 of its row) in
+    // registers: fragment-shaped requests (16 rows x 4 separate pieces per instruction) cost the texture-address unit
+    // four times the line look-ups per byte, which bounded this kernel at ~2 TB/s (tools/probe_mid.py has the bf16 case).
+    const int lr8 = lane >> 3, pc = (lane & 7) * 16;
+    auto line_ptr = [&](const uint8_t* base, int row, int rows) __attribute__((always_inline)) {
+        row = row < rows ? row : rows - 1;
+        return base + (size_t)row * a.K + pc;
+    };
+    const uint8_t* wl[2] = {line_ptr(a.w, n0 + lr8, a.N), line_ptr(a.w, n0 + 8 + lr8, a.N)};
+    const uint8_t* wl2[2] = {SW ? line_ptr(a.w2, n0 + lr8, a.N) : nullptr, SW ? line_ptr(a.w2, n0 + 8 + lr8, a.N) : nullptr};
+    const uint8_t* xl4[NG][4];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        int m_lo = g * 32 + lrow, m_hi = g * 32 + 16 + lrow;
-        m_lo = m_lo < a.M ? m_lo : a.M - 1;
-        m_hi = m_hi < a.M ? m_hi : a.M - 1;
-        xlo[g] = a.x + (size_t)m_lo * a.K + kg * 32;
-        xhi[g] = a.x + (size_t)m_hi * a.K + kg * 32;
-    }
-    auto ldw = [](const uint8_t* p) __attribute__((always_inline)) -> i32x8 {
-        const i32x4 lo = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(p));
-        const i32x4 hi = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(p + 16));
-        return i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int h = 0; h < 4; ++h) xl4[g][h] = line_ptr(a.x, g * 32 + h * 8 + lr8, a.M);
+    // even pieces of both requests in one register (odd lanes take the second request's even piece from the lane
+    // below), odd pieces in another; fragment lane (r, kg) then reads lane 8(r%8) + 2kg + r/8 of each
+    const int fidx = ((lrow & 7) * 8 + 2 * kg + (lrow >> 3)) * 4;
+    auto frag = [&](const i32x4& r0, const i32x4& r1) __attribute__((always_inline)) -> i32x8 {
+        i32x8 f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int ev = __builtin_amdgcn_update_dpp(r0[d], r1[d], 0x111 /* row_shr:1 */, 0xF, 0xA /* odd lanes */, false);
+            const int od = __builtin_amdgcn_update_dpp(r1[d], r0[d], 0x101 /* row_shl:1 */, 0xF, 0x5 /* even lanes */, false);
+            f[d] = __builtin_amdgcn_ds_bpermute(fidx, ev);
+            f[4 + d] = __builtin_amdgcn_ds_bpermute(fidx, od);
+        }
+        return f;
     };
-    auto ldx = [](const uint8_t* p) __attribute__((always_inline)) -> i32x8 {
-        const uint4 lo = *reinterpret_cast<const uint4*>(p);
-        const uint4 hi = *reinterpret_cast<const uint4*>(p + 16);
-        return i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
-    };
+    auto ldnt = [](const uint8_t* p) __attribute__((always_inline)) { return __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(p)); };
+    auto ld = [](const uint8_t* p) __attribute__((always_inline)) { return *reinterpret_cast<const i32x4*>(p); };
     f32x4 acc_lo[NG], acc_hi[NG], acc2_lo[SW ? NG : 1], acc2_hi[SW ? NG : 1];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -407,36 +415,42 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_skinny_kernel(Fp8Args a) {
     }
     const int nks = a.K / 128;
     for (int ks0 = wave; ks0 < nks; ks0 += NW * CH) {
-        i32x8 wf[CH], wf2[SW ? CH : 1];
+        i32x4 wr[CH][2], wr2[SW ? CH : 1][2];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const int ks = ks0 + c * NW;
             if (ks < nks) {
-                wf[c] = ldw(wrow + (size_t)ks * 128);
-                if (SW) wf2[c] = ldw(wrow2 + (size_t)ks * 128);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    wr[c][h] = ldnt(wl[h] + (size_t)ks * 128);
+                    if (SW) wr2[c][h] = ldnt(wl2[h] + (size_t)ks * 128);
+                }
             }
         }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             if (g * 32 >= a.M) break;
-            i32x8 xl[CH], xh[CH];
+            i32x4 xr[CH][4];
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
                 const int ks = ks0 + c * NW;
                 if (ks < nks) {
-                    xl[c] = ldx(xlo[g] + (size_t)ks * 128);
-                    xh[c] = ldx(xhi[g] + (size_t)ks * 128);
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) xr[c][h] = ld(xl4[g][h] + (size_t)ks * 128);
                 }
             }
 #pragma unroll
             for (int c = 0; c < CH; ++c) {
                 const int ks = ks0 + c * NW;
                 if (ks < nks) {
-                    acc_lo[g] = mfma_fp8(wf[c], xl[c], acc_lo[g]);
-                    acc_hi[g] = mfma_fp8(wf[c], xh[c], acc_hi[g]);
+                    const i32x8 wf = frag(wr[c][0], wr[c][1]);
+                    const i32x8 xl = frag(xr[c][0], xr[c][1]), xh = frag(xr[c][2], xr[c][3]);
+                    acc_lo[g] = mfma_fp8(wf, xl, acc_lo[g]);
+                    acc_hi[g] = mfma_fp8(wf, xh, acc_hi[g]);
                     if (SW) {
-                        acc2_lo[g] = mfma_fp8(wf2[c], xl[c], acc2_lo[g]);
-                        acc2_hi[g] = mfma_fp8(wf2[c], xh[c], acc2_hi[g]);
+                        const i32x8 wf2 = frag(wr2[c][0], wr2[c][1]);
+                        acc2_lo[g] = mfma_fp8(wf2, xl, acc2_lo[g]);
+                        acc2_hi[g] = mfma_fp8(wf2, xh, acc2_hi[g]);
                     }
                 }
             }
