@@ -53,6 +53,27 @@ __device__ __forceinline__ void glds16_nt(const void* gsrc, void* lds_wave_base)
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2);
 }
 
+// ---- full-line loads -> MFMA fragments, in registers ------------------------------------------------------
+// A 16-row x 128-B operand block fetched as two requests of full lines (request h: rows 8h..8h+7, lane -> row lane/8,
+// 16-B piece lane%8 of the row's line) holds, for the 16x16 MFMA forms whose lane (row r = lane%16, kg = lane/16) wants
+// 16-B piece 4t + kg of row r (bf16 x32: t = k-step 0/1 of the line), the 64 pieces of fragment t on the lanes with
+// (lane & 4) == 4t of both requests.  One DPP move merges them (DPP bank masks cover lanes in fours), one ds_bpermute
+// per dword puts them in fragment order: source lane 8 (r%8) + kg + 4 (r/8) for both fragments.
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+__device__ __forceinline__ int frag_src_lane(int lane) { return ((lane & 7) << 3) + (lane >> 4) + (((lane >> 3) & 1) << 2); }
+__device__ __forceinline__ void lines_to_frags(const i32x4& r0, const i32x4& r1, int fidx, bf16x8& f0, bf16x8& f1) {
+    union { i32x4 i; bf16x8 b; } a, b;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int lo = __builtin_amdgcn_update_dpp(r0[d], r1[d], 0x114 /* row_shr:4 */, 0xF, 0xA /* lanes 4-7, 12-15 of a row */, false);
+        const int hi = __builtin_amdgcn_update_dpp(r1[d], r0[d], 0x104 /* row_shl:4 */, 0xF, 0x5 /* lanes 0-3, 8-11 */, false);
+        a.i[d] = __builtin_amdgcn_ds_bpermute(fidx, lo);
+        b.i[d] = __builtin_amdgcn_ds_bpermute(fidx, hi);
+    }
+    f0 = a.b;
+    f1 = b.b;
+}
+
 // ---- KV cache in MFMA-fragment order --------------------------------------------------------
 // Both caches are stored per (slot, group) as 32-key tiles of HS*32 elements, laid out so that a
 // wave-wide contiguous 1-KiB load (lane i <- 16 B at i*16) IS an MFMA operand fragment:

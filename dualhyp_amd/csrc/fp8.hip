@@ -376,10 +376,10 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_skinny_kernel(Fp8Args a) {
     const int n0 = blockIdx.x * ROWS;
     const int lrow = lane & 15, kg = lane >> 4;
     // Operands are fetched as FULL 128-B lines — request h covers rows 8h..8h+7 of a 16-row block, lane -> (row lane/8,
-    // 16-B piece lane%8) — and turned into MFMA fragments (lane (row, kg) holds pieces 2kg, 2kg+1 of its row) in
+    // 16-B piece: the four even pieces on lanes 0-3 of the row's eight, the odd ones on lanes 4-7) — and turned into MFMA fragments (lane (row, kg) holds pieces 2kg, 2kg+1 of its row) in
     // registers: fragment-shaped requests (16 rows x 4 separate pieces per instruction) cost the texture-address unit
     // four times the line look-ups per byte, which bounded this kernel at ~2 TB/s (tools/probe_mid.py has the bf16 case).
-    const int lr8 = lane >> 3, pc = (lane & 7) * 16;
+    const int lr8 = lane >> 3, pc = (((lane & 3) << 1) | ((lane >> 2) & 1)) * 16;
     auto line_ptr = [&](const uint8_t* base, int row, int rows) __attribute__((always_inline)) {
         row = row < rows ? row : rows - 1;
         return base + (size_t)row * a.K + pc;
@@ -391,15 +391,16 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_skinny_kernel(Fp8Args a) {
     for (int g = 0; g < NG; ++g)
 #pragma unroll
         for (int h = 0; h < 4; ++h) xl4[g][h] = line_ptr(a.x, g * 32 + h * 8 + lr8, a.M);
-    // even pieces of both requests in one register (odd lanes take the second request's even piece from the lane
-    // below), odd pieces in another; fragment lane (r, kg) then reads lane 8(r%8) + 2kg + r/8 of each
-    const int fidx = ((lrow & 7) * 8 + 2 * kg + (lrow >> 3)) * 4;
+    // even pieces of both requests in one register (lanes 4-7 of each eight take the second request's even pieces from
+    // four lanes below: DPP bank masks cover lanes in fours), odd pieces in another; fragment lane (r, kg) then reads
+    // lane 8(r%8) + kg + 4(r/8) of each
+    const int fidx = ((lrow & 7) * 8 + kg + 4 * (lrow >> 3)) * 4;
     auto frag = [&](const i32x4& r0, const i32x4& r1) __attribute__((always_inline)) -> i32x8 {
         i32x8 f;
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
-            const int ev = __builtin_amdgcn_update_dpp(r0[d], r1[d], 0x111 /* row_shr:1 */, 0xF, 0xA /* odd lanes */, false);
-            const int od = __builtin_amdgcn_update_dpp(r1[d], r0[d], 0x101 /* row_shl:1 */, 0xF, 0x5 /* even lanes */, false);
+            const int ev = __builtin_amdgcn_update_dpp(r0[d], r1[d], 0x114 /* row_shr:4 */, 0xF, 0xA /* lanes 4-7, 12-15 */, false);
+            const int od = __builtin_amdgcn_update_dpp(r1[d], r0[d], 0x104 /* row_shl:4 */, 0xF, 0x5 /* lanes 0-3, 8-11 */, false);
             f[d] = __builtin_amdgcn_ds_bpermute(fidx, ev);
             f[4 + d] = __builtin_amdgcn_ds_bpermute(fidx, od);
         }

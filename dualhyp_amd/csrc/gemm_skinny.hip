@@ -286,15 +286,30 @@ __global__ __launch_bounds__(512, NG == 1 ? 2 : 1) void gemm_skinny_rows_kernel(
     const int nks = K / 32;
     const int ks_begin = blockIdx.y * KPS;
     const int ks_cnt = min(KPS, nks - ks_begin);          // >= 1 by construction of the grid
+    // W is fetched as full 128-B lines (request: rows 8h..8h+7 of the tile x two k-steps, lane -> (row lane/8, 16-B piece
+    // lane%8)) and transposed into MFMA fragments in registers (lines_to_frags, common.h): fragment-shaped requests
+    // (16 rows x 64 B) cost the texture-address unit four times the line look-ups per byte.
+    static_assert(KPS % 2 == 0, "a line holds two k-steps");
     bf16x8 wf[CT][KPS];
+    {
+        i32x4 raw[CT][KPS / 2][2];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-        int n = n0 + ct * 16 + lrow;
-        n = n < N ? n : N - 1;
-        const bf16_t* wrow = (n < n_main ? w + (size_t)n * K : w_ext + (size_t)(n - n_main) * K) + ks_begin * 32 + kg * 8;
+        for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-        for (int c = 0; c < KPS; ++c)
-            if (c < ks_cnt) wf[ct][c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wrow + c * 32));
+            for (int h = 0; h < 2; ++h) {
+                int n = n0 + ct * 16 + h * 8 + (lane >> 3);
+                n = n < N ? n : N - 1;
+                const bf16_t* wrow = (n < n_main ? w + (size_t)n * K : w_ext + (size_t)(n - n_main) * K) + ks_begin * 32 + (lane & 7) * 8;
+#pragma unroll
+                for (int c2 = 0; c2 < KPS / 2; ++c2)
+                    if (2 * c2 < ks_cnt) raw[ct][c2][h] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wrow + c2 * 64));
+            }
+        const int fidx = frag_src_lane(lane) * 4;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int c2 = 0; c2 < KPS / 2; ++c2)
+                if (2 * c2 < ks_cnt) lines_to_frags(raw[ct][c2][0], raw[ct][c2][1], fidx, wf[ct][2 * c2], wf[ct][2 * c2 + 1]);
     }
 #pragma unroll
     for (int r0 = 0; r0 < NG; r0 += NGL) {
@@ -416,7 +431,7 @@ extern "C" int dh_linear_partial_bf16(const dh_bf16* x, const dh_bf16* w, const 
     const int kps = (nks + ksplit - 1) / ksplit;
     hipStream_t s = (hipStream_t)stream;
     // the kernel is a function of (K, ksplit) alone, never of M: rows of a larger call equal the same rows alone
-    if (g_skinny_variant == 1 && (kps == 8 || kps == 16) && (ksplit - 1) * kps < nks && N % 4 == 0) {
+    if (g_skinny_variant == 1 && (kps == 8 || kps == 16) && (ksplit - 1) * kps < nks && N % 4 == 0 && K % 64 == 0) {
         if (kps == 8) return launch_rows_ng<8>(x, w, w_ext ? w_ext : w, y32, M, n_main, N, K, ksplit, s);
         return launch_rows_ng<16>(x, w, w_ext ? w_ext : w, y32, M, n_main, N, K, ksplit, s);
     }
