@@ -21,12 +21,13 @@
 #include "gemm.h"
 
 int g_dt_stages = 0;   // 0: by grid size, else 2 or 4 (dh_set_tuning key 8)
+int g_dt_wide = 0;     // SwiGLU tile of 128 pairs x 128 rows on 8 waves: 0 = from 256 rows on, 1 = always, -1 = never (dh_set_tuning key 15)
 
 namespace {
 
-constexpr int TB = 128;                 // block tile edge (rows of x, rows of W)
+constexpr int TB = 128;                 // rows of x per block tile; rows of W per block: 64 * WN (WN = waves along n)
 constexpr int BKD = 64;                 // K per stage (two k-steps of 32)
-constexpr int STAGE = 2 * TB * BKD * 2; // bytes per stage: W tile 16 KiB + x tile 16 KiB
+template <int WN> constexpr int stage_bytes() { return (WN * 64 + TB) * BKD * 2; }   // W tile 8 KiB * WN + x tile 16 KiB
 
 __device__ __forceinline__ int swz7(int row) { return (row >> 1) & 7; }
 
@@ -41,56 +42,78 @@ struct DtArgs {
     int M, N, K, n_main, seg;   // seg: k-steps per chain segment (even)
 };
 
-template <int MODE, int NSTAGE>   // NSTAGE 4: one block per CU, 3 stages in flight; NSTAGE 2: two blocks per CU
-__global__ __launch_bounds__(256) void gemm_dt_kernel(DtArgs a) {
+// NSTAGE 4: one block per CU, 3 stages in flight; NSTAGE 2: two blocks per CU.  WN 2: 4 waves, 128 W rows per block;
+// WN 4 (SwiGLU at >= 256 rows): 8 waves, 256 W rows (128 fc_1/fc_2 pairs) per block, 3 stages of 48 KiB — half the
+// blocks, each moving 1.5x the bytes per stage for 2x the MFMA work (a block's time is set by its stage count, not by
+// the bytes: ~1 us per stage of LDS-DMA latency), and 640 rows become one round of 220 blocks instead of 440.
+template <int MODE, int NSTAGE, int WN = 2>
+__global__ __launch_bounds__(WN * 128) void gemm_dt_kernel(DtArgs a) {
+    constexpr int STAGE = stage_bytes<WN>();
+    constexpr int ASZ = WN * 64 * BKD * 2;                        // bytes of the W tile of a stage
+    constexpr int NB = 16 / (2 * WN);                             // x groups (8 rows x 128 B) staged per wave
+    constexpr int PER = 4 + NB;                                   // LDS-DMA requests per wave and stage
     extern __shared__ __attribute__((aligned(16))) char smem[];   // NSTAGE stages
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wm = wave & 1;
     const int frow = lane & 15, kg = lane >> 4;
     const int m_tiles = (a.M + TB - 1) / TB;
-    const int tm = blockIdx.x % m_tiles, tn = blockIdx.x / m_tiles;
+    // XCD-aware order (blocks go round-robin over the 8 XCDs, each with its own L2): an XCD walks a CONTIGUOUS range of
+    // the m-fastest tile order, so the m-tiles that share a W tile meet in one L2 instead of fetching it over the fabric
+    // once per XCD (at 640 rows that was 5 x 46 MB per SwiGLU launch = 5.2 TB/s: the limit of the kernel).
+    int tile;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tm = tile % m_tiles, tn = tile / m_tiles;
     const int m0 = tm * TB;
-    const int n0 = MODE == 1 ? tn * 64 : tn * TB;     // first output column of the block
+    const int n0 = MODE == 1 ? tn * (WN * 32) : tn * (WN * 64);     // first output column of the block
 
-    // ---- staging sources: 16 + 16 one-KiB groups (8 rows of 128 B) per stage, 4 + 4 per wave
+    // ---- staging sources: 8 WN + 16 one-KiB groups (8 rows of 128 B) per stage, 4 + NB per wave
     const bf16_t* srcA[4];
-    const bf16_t* srcB[4];
+    const bf16_t* srcB[NB];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int R = wave * 4 + j;
         const int row = R * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ swz7(row);
-        {
-            const bf16_t* base = a.w;
-            int n;
-            if (MODE == 1) {
-                // a wave's 64 LDS rows: 32 rows of fc_1 then the same 32 rows of fc_2
-                const int half = (row >> 5) & 1;
-                n = n0 + (row >> 6) * 32 + (row & 31);
-                n = n < a.N ? n : a.N - 1;
-                base = half ? a.w2 : a.w;
-            } else {
-                n = n0 + row;
-                n = n < a.N ? n : a.N - 1;
-                if (MODE == 0 && n >= a.n_main) { base = a.w2; n -= a.n_main; }
-            }
-            srcA[j] = base + (size_t)n * a.K + chunk * 8;
+        const bf16_t* base = a.w;
+        int n;
+        if (MODE == 1) {
+            // a wave's 64 LDS rows: 32 rows of fc_1 then the same 32 rows of fc_2
+            const int half = (row >> 5) & 1;
+            n = n0 + (row >> 6) * 32 + (row & 31);
+            n = n < a.N ? n : a.N - 1;
+            base = half ? a.w2 : a.w;
+        } else {
+            n = n0 + row;
+            n = n < a.N ? n : a.N - 1;
+            if (MODE == 0 && n >= a.n_main) { base = a.w2; n -= a.n_main; }
         }
-        {
-            int m = m0 + row;
-            m = m < a.M ? m : a.M - 1;
-            srcB[j] = a.x + (size_t)m * a.K + chunk * 8;
-        }
+        srcA[j] = base + (size_t)n * a.K + chunk * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int R = wave * NB + j;
+        const int row = R * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ swz7(row);
+        int m = m0 + row;
+        m = m < a.M ? m : a.M - 1;
+        srcB[j] = a.x + (size_t)m * a.K + chunk * 8;
     }
     auto stage = [&](int kt) __attribute__((always_inline)) {
         char* sA = smem + (kt % NSTAGE) * STAGE;
-        char* sB = sA + STAGE / 2;
+        char* sB = sA + ASZ;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int R = wave * 4 + j;
-            glds16(srcA[j] + kt * BKD, sA + R * 1024);
-            glds16(srcB[j] + kt * BKD, sB + R * 1024);
-        }
+        for (int j = 0; j < 4; ++j) glds16(srcA[j] + kt * BKD, sA + (wave * 4 + j) * 1024);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) glds16(srcB[j] + kt * BKD, sB + (wave * NB + j) * 1024);
+    };
+    // stage kt+1 landed (this wave's share) while up to `ahead` younger stages stay in flight
+    auto wait_next = [&](int ahead) __attribute__((always_inline)) {
+        if (NSTAGE >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+        else if (NSTAGE >= 3 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
 
     f32x4 cur[4][4], tot[4][4];
@@ -110,16 +133,14 @@ __global__ __launch_bounds__(256) void gemm_dt_kernel(DtArgs a) {
 #pragma unroll
     for (int p = 0; p < NSTAGE - 1; ++p)
         if (p < nk) stage(p);
-    if (NSTAGE == 4 && 2 < nk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (NSTAGE == 4 && 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_next((nk < NSTAGE - 1 ? nk : NSTAGE - 1) - 1);
     __builtin_amdgcn_s_barrier();
     int in_seg = 0;
     for (int kt = 0; kt < nk; ++kt) {
         // ring slot (kt+NSTAGE-1) % NSTAGE was last read in iteration kt-1, which ended with a barrier
         if (kt + NSTAGE - 1 < nk) stage(kt + NSTAGE - 1);
         const char* sA = smem + (kt % NSTAGE) * STAGE;
-        const char* sB = sA + STAGE / 2;
+        const char* sB = sA + ASZ;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int co = ((ks * 4 + kg) ^ sw) << 4;
@@ -146,9 +167,10 @@ __global__ __launch_bounds__(256) void gemm_dt_kernel(DtArgs a) {
                 }
         }
         // own share of stage kt+1 landed (later stages may stay in flight), then everybody's
-        if (NSTAGE == 4 && kt + 3 < nk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if (NSTAGE == 4 && kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        {
+            const int issued = (kt + NSTAGE - 1 < nk ? kt + NSTAGE - 1 : nk - 1);   // youngest stage requested so far
+            wait_next(issued - (kt + 1));
+        }
         __builtin_amdgcn_s_barrier();
     }
 
@@ -198,18 +220,21 @@ __global__ __launch_bounds__(256) void gemm_dt_kernel(DtArgs a) {
     }
 }
 
-template <int MODE, int NSTAGE>
+template <int MODE, int NSTAGE, int WN = 2>
 int launch_dt_n(const DtArgs& a, int blocks, hipStream_t s) {
-    constexpr int lds = NSTAGE * STAGE;     // 128 KiB / 64 KiB
-    DH_MAX_LDS_ONCE((gemm_dt_kernel<MODE, NSTAGE>), lds);
-    hipLaunchKernelGGL((gemm_dt_kernel<MODE, NSTAGE>), dim3(blocks), dim3(256), lds, s, a);
+    constexpr int lds = NSTAGE * stage_bytes<WN>();     // WN 2: 128 KiB / 64 KiB; WN 4: 144 KiB
+    DH_MAX_LDS_ONCE((gemm_dt_kernel<MODE, NSTAGE, WN>), lds);
+    hipLaunchKernelGGL((gemm_dt_kernel<MODE, NSTAGE, WN>), dim3(blocks), dim3(WN * 128), lds, s, a);
     DH_LAUNCH_CHECK();
     return 0;
 }
 
 template <int MODE>
 int launch_dt(const DtArgs& a, hipStream_t s) {
-    const int m_tiles = cdiv(a.M, TB), n_tiles = cdiv(a.N, MODE == 1 ? 64 : TB);
+    const int m_tiles = cdiv(a.M, TB);
+    if (MODE == 1 && (g_dt_wide ? g_dt_wide > 0 : a.M >= 256))
+        return launch_dt_n<1, 3, 4>(a, m_tiles * cdiv(a.N, 128), s);
+    const int n_tiles = cdiv(a.N, MODE == 1 ? 64 : TB);
     const int blocks = m_tiles * n_tiles;
     // more than one block per CU to go round: two co-resident blocks hide each other's waits better than
     // a deeper ring in one block
