@@ -74,6 +74,21 @@ __device__ __forceinline__ void lines_to_frags(const i32x4& r0, const i32x4& r1,
     f1 = b.b;
 }
 
+// The inverse, for 16x16 accumulator tiles on their way to memory: two C^T tiles of 16 columns (t = 0 / 1) x 16 rows, lane
+// (row r = lane%16, kg = lane/16) holding columns 16t + 4kg..+4 of row r, become two requests of full 128-B lines (r0: rows
+// 0..7, r1: rows 8..15; lane -> row lane/8, columns 4 (lane%8)..+4 of the 32).  Stores of 16 rows x 64 B per instruction
+// pay per 64-B segment like fragment-shaped loads do.
+__device__ __forceinline__ int line_src_lane(int lane) { return ((lane & 3) << 4) | (((lane >> 2) & 1) << 3) | (lane >> 3); }
+__device__ __forceinline__ void tiles_to_lines(const f32x4& t0, const f32x4& t1, int lidx, f32x4& r0, f32x4& r1) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int m0 = __builtin_amdgcn_ds_bpermute(lidx, __float_as_int(t0[d]));
+        const int m1 = __builtin_amdgcn_ds_bpermute(lidx, __float_as_int(t1[d]));
+        r0[d] = __int_as_float(__builtin_amdgcn_update_dpp(m0, m1, 0x114 /* row_shr:4 */, 0xF, 0xA, false));
+        r1[d] = __int_as_float(__builtin_amdgcn_update_dpp(m1, m0, 0x104 /* row_shl:4 */, 0xF, 0x5, false));
+    }
+}
+
 // ---- KV cache in MFMA-fragment order --------------------------------------------------------
 // Both caches are stored per (slot, group) as 32-key tiles of HS*32 elements, laid out so that a
 // wave-wide contiguous 1-KiB load (lane i <- 16 B at i*16) IS an MFMA operand fragment:

@@ -271,94 +271,145 @@ __global__ __launch_bounds__(512, 2) void gemm_skinny_partial_kernel(const bf16_
 // LDS port, not the weight stream, bounds the kernel (rocprof at 640 rows: 275-316 TFLOP/s); with CT tiles one x
 // fragment feeds CT MFMAs.  The summation order is untouched: same K-slices, same chain inside a slice.
 //   grid (ceil(N/(128*CT)), ksplit, ceil(M / (32*NG))), K-slice = KPS k-steps of 32.
+#ifdef DH_ROWS_STAMPS   // diagnostic build only (tools/probe_rows.py): 100 MHz timestamps of wave 0 per block
+__device__ unsigned long long g_rows_stamps[1024 * 8];
+#define ROWS_STAMP(i) do { if (threadIdx.x == 0) { const int _b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
+    if (_b < 1024) g_rows_stamps[_b * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+extern "C" int dh_debug_rows_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rows_stamps), sizeof(g_rows_stamps)) == hipSuccess ? 0 : 1;
+}
+#else
+#define ROWS_STAMP(i)
+#endif
+
 template <int KPS, int NG, int NGL, int CT>
 __global__ __launch_bounds__(512, NG == 1 ? 2 : 1) void gemm_skinny_rows_kernel(const bf16_t* __restrict__ x,
                                                                               const bf16_t* __restrict__ w,
                                                                               const bf16_t* __restrict__ w_ext,
                                                                               float* __restrict__ y32, int M, int n_main,
                                                                               int N, int K) {
-    constexpr int XS = KPS * 64 + 16;                      // padded row stride of the x slice (bytes)
-    extern __shared__ __attribute__((aligned(16))) char sx[];   // [NGL*32][XS]
+    // x passes through LDS in ROUNDS of NGL 32-row groups, two buffers: round r+1 is requested (LDS-DMA, 16 B per lane,
+    // rows of KPS*64 B with the 16-B chunk index XOR (row & 15) applied on the SOURCE address so the fragment reads are
+    // conflict free) before the MFMAs of round r, and waited for after them — the wait also covers the partial-sum
+    // stores of round r-1 (loads and stores share vmcnt and complete out of order with each other), so the stores of
+    // round r are issued after it and drain under round r+1.  One barrier per round.  K-slices are whole (host check).
+    constexpr int RB = KPS * 64;                           // bytes of an x row of the slice
+    constexpr int RND = NGL * 32 * RB;                     // bytes of a round buffer
+    constexpr int LPR = RB / 16;                           // lanes (16-B chunks) per row: 32 or 64
+    constexpr int XI = RND / 1024 / 8;                     // LDS-DMA requests per wave and round
+    constexpr int NR = (NG + NGL - 1) / NGL;               // rounds
+    static_assert(KPS % 2 == 0 && RND % 8192 == 0, "a line holds two k-steps; a round is a whole number of requests per wave");
+    extern __shared__ __attribute__((aligned(16))) char sx[];   // [2][NGL*32][RB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, kg = lane >> 4;
     const int n0 = blockIdx.x * (128 * CT) + wave * (16 * CT);
     const int m0 = blockIdx.z * (NG * 32);
-    const int nks = K / 32;
     const int ks_begin = blockIdx.y * KPS;
-    const int ks_cnt = min(KPS, nks - ks_begin);          // >= 1 by construction of the grid
-    // W is fetched as full 128-B lines (request: rows 8h..8h+7 of the tile x two k-steps, lane -> (row lane/8, 16-B piece
-    // lane%8)) and transposed into MFMA fragments in registers (lines_to_frags, common.h): fragment-shaped requests
-    // (16 rows x 64 B) cost the texture-address unit four times the line look-ups per byte.
-    static_assert(KPS % 2 == 0, "a line holds two k-steps");
+    ROWS_STAMP(0);
+    // W: full 128-B lines (request: rows 8h..8h+7 of the tile x two k-steps, lane -> (row lane/8, 16-B piece lane%8)),
+    // transposed into MFMA fragments in registers (lines_to_frags, common.h): fragment-shaped requests (16 rows x 64 B)
+    // cost the texture-address unit four times the line look-ups per byte.
+    i32x4 raw[CT][KPS / 2][2];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int n = n0 + ct * 16 + h * 8 + (lane >> 3);
+            n = n < N ? n : N - 1;
+            const bf16_t* wrow = (n < n_main ? w + (size_t)n * K : w_ext + (size_t)(n - n_main) * K) + ks_begin * 32 + (lane & 7) * 8;
+#pragma unroll
+            for (int c2 = 0; c2 < KPS / 2; ++c2) raw[ct][c2][h] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wrow + c2 * 64));
+        }
+    // request q of a round covers LDS bytes [q KiB, (q+1) KiB): row q*(64/LPR) + lane/LPR, chunk position lane%LPR
+    const int xrow_in = lane / LPR, xpos = lane % LPR;
+    auto issue_x = [&](int r) __attribute__((always_inline)) {
+        char* buf = sx + (r & 1) * RND;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int q = wave + 8 * i;
+            const int row = q * (64 / LPR) + xrow_in;              // row of the round
+            int m = m0 + r * (NGL * 32) + row;
+            m = m < M ? m : M - 1;
+            const int chunk = xpos ^ (row & 15);
+            glds16(x + (size_t)m * K + ks_begin * 32 + chunk * 8, buf + q * 1024);
+        }
+    };
+    const int rounds = min(NR, (M - m0 + NGL * 32 - 1) / (NGL * 32));   // >= 1 by construction of the grid
+    issue_x(0);
     bf16x8 wf[CT][KPS];
     {
-        i32x4 raw[CT][KPS / 2][2];
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                int n = n0 + ct * 16 + h * 8 + (lane >> 3);
-                n = n < N ? n : N - 1;
-                const bf16_t* wrow = (n < n_main ? w + (size_t)n * K : w_ext + (size_t)(n - n_main) * K) + ks_begin * 32 + (lane & 7) * 8;
-#pragma unroll
-                for (int c2 = 0; c2 < KPS / 2; ++c2)
-                    if (2 * c2 < ks_cnt) raw[ct][c2][h] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wrow + c2 * 64));
-            }
         const int fidx = frag_src_lane(lane) * 4;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-            for (int c2 = 0; c2 < KPS / 2; ++c2)
-                if (2 * c2 < ks_cnt) lines_to_frags(raw[ct][c2][0], raw[ct][c2][1], fidx, wf[ct][2 * c2], wf[ct][2 * c2 + 1]);
+            for (int c2 = 0; c2 < KPS / 2; ++c2) lines_to_frags(raw[ct][c2][0], raw[ct][c2][1], fidx, wf[ct][2 * c2], wf[ct][2 * c2 + 1]);
     }
+    ROWS_STAMP(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // round 0 is in LDS
+    ROWS_STAMP(2);
+    float* out = y32 + (size_t)blockIdx.y * M * N;
 #pragma unroll
-    for (int r0 = 0; r0 < NG; r0 += NGL) {
-        const int mr = m0 + r0 * 32;                       // first row of this LDS round
-        if (mr >= M) break;
-        if (r0 > 0) __syncthreads();                       // the previous round's fragment reads are done
-        // stage the x slice: 32*NGL rows x ks_cnt*4 chunks of 16 B
-#pragma unroll
-        for (int i = 0; i < NGL * 32 * KPS * 4 / 512; ++i) {
-            const int c = tid + i * 512;
-            const int row = c / (KPS * 4), col = c % (KPS * 4);
-            if (col < ks_cnt * 4 && r0 * 32 + row < NG * 32) {     // (the last round may hold fewer than NGL groups)
-                int m = mr + row;
-                m = m < M ? m : M - 1;
-                *reinterpret_cast<uint4*>(sx + row * XS + col * 16) =
-                    *reinterpret_cast<const uint4*>(x + (size_t)m * K + ks_begin * 32 + col * 8);
-            }
-        }
-        __syncthreads();
+    for (int r = 0; r < NR; ++r) {
+        if (r >= rounds) break;
+        if (r + 1 < rounds) issue_x(r + 1);                // its buffer was last read in round r-1, which ended with a barrier
+        const char* buf = sx + (r & 1) * RND;
+        f32x4 acc_lo[NGL][CT], acc_hi[NGL][CT];
 #pragma unroll
         for (int g = 0; g < NGL; ++g) {
-            const int mg = mr + g * 32;
-            if (mg >= M || r0 + g >= NG) break;
-            f32x4 acc_lo[CT], acc_hi[CT];
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) acc_lo[ct] = acc_hi[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ct = 0; ct < CT; ++ct) acc_lo[g][ct] = acc_hi[g][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r * NGL + g < NG && m0 + (r * NGL + g) * 32 < M) {
 #pragma unroll
-            for (int c = 0; c < KPS; ++c) {
-                if (c < ks_cnt) {
-                    const bf16x8 xl = *reinterpret_cast<const bf16x8*>(sx + (g * 32 + lrow) * XS + c * 64 + kg * 16);
-                    const bf16x8 xh = *reinterpret_cast<const bf16x8*>(sx + (g * 32 + 16 + lrow) * XS + c * 64 + kg * 16);
+                for (int c = 0; c < KPS; ++c) {
+                    const int co = ((c * 4 + kg) ^ lrow) << 4;
+                    const bf16x8 xl = *reinterpret_cast<const bf16x8*>(buf + (g * 32 + lrow) * RB + co);
+                    const bf16x8 xh = *reinterpret_cast<const bf16x8*>(buf + (g * 32 + 16 + lrow) * RB + co);
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct) {
-                        acc_lo[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][c], xl, acc_lo[ct], 0, 0, 0);
-                        acc_hi[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][c], xh, acc_hi[ct], 0, 0, 0);
+                        acc_lo[g][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][c], xl, acc_lo[g][ct], 0, 0, 0);
+                        acc_hi[g][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ct][c], xh, acc_hi[g][ct], 0, 0, 0);
                     }
                 }
             }
+        }
+        if (r + 1 < rounds) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // round r+1 landed (this wave's share), round r-1's stores done
+            __builtin_amdgcn_s_barrier();                      // ... everybody's; and everybody has read round r
+        }
+        ROWS_STAMP(r == 0 ? 3 : 5);
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const int nn = n0 + ct * 16 + kg * 4;
-                if (nn < N) {
-                    float* out = y32 + (size_t)blockIdx.y * M * N + nn;
-                    if (mg + lrow < M) *reinterpret_cast<f32x4*>(out + (size_t)(mg + lrow) * N) = acc_lo[ct];
-                    if (mg + 16 + lrow < M) *reinterpret_cast<f32x4*>(out + (size_t)(mg + 16 + lrow) * N) = acc_hi[ct];
+        for (int g = 0; g < NGL; ++g) {
+            const int mg = m0 + (r * NGL + g) * 32;
+            if (r * NGL + g >= NG || mg >= M) break;
+            if (CT >= 2 && n0 + 16 * CT <= N) {
+                // full 128-B lines: the wave's adjacent 16-column tiles are stored as rows of 32 columns
+                const int lidx = line_src_lane(lane) * 4;
+#pragma unroll
+                for (int cp = 0; cp + 1 < CT; cp += 2) {
+                    float* o = out + n0 + cp * 16 + (lane & 7) * 4;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {              // rows mg..mg+15, then mg+16..mg+31
+                        f32x4 r0, r1;
+                        tiles_to_lines(h ? acc_hi[g][cp] : acc_lo[g][cp], h ? acc_hi[g][cp + 1] : acc_lo[g][cp + 1], lidx, r0, r1);
+                        const int m_a = mg + h * 16 + (lane >> 3), m_b = m_a + 8;
+                        if (m_a < M) *reinterpret_cast<f32x4*>(o + (size_t)m_a * N) = r0;
+                        if (m_b < M) *reinterpret_cast<f32x4*>(o + (size_t)m_b * N) = r1;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int nn = n0 + ct * 16 + kg * 4;
+                    if (nn < N) {
+                        if (mg + lrow < M) *reinterpret_cast<f32x4*>(out + (size_t)(mg + lrow) * N + nn) = acc_lo[g][ct];
+                        if (mg + 16 + lrow < M) *reinterpret_cast<f32x4*>(out + (size_t)(mg + 16 + lrow) * N + nn) = acc_hi[g][ct];
+                    }
                 }
             }
         }
     }
+    ROWS_STAMP(6);
 }
 
 int g_rows_ng = 0;   // 0: by grid size; 8 or 10 row groups per block above 128 rows (dh_set_tuning key 14)
@@ -367,10 +418,9 @@ int g_rows_ct = 0;   // 0: by row count; else forced column tiles per wave (dh_s
 template <int KPS, int NG, int CT>
 int launch_rows(const bf16_t* x, const bf16_t* w, const bf16_t* w_ext, float* y32, int M, int n_main, int N, int K,
                 int ksplit, hipStream_t s) {
-    constexpr int XS = KPS * 64 + 16;
-    constexpr int NGL = NG * 32 * XS <= 144 * 1024 ? NG : (NG / 2 * 32 * XS <= 144 * 1024 ? NG / 2 : 4);   // groups resident in LDS at once
-    constexpr int lds = NGL * 32 * XS;
-    static_assert(lds <= 160 * 1024, "x slice does not fit in LDS");
+    constexpr int NGL = NG == 1 ? 1 : (KPS == 8 ? (NG >= 4 ? 4 : 2) : 2);   // row groups per LDS round (two round buffers)
+    constexpr int lds = 2 * NGL * 32 * KPS * 64;
+    static_assert(lds <= 160 * 1024, "x rounds do not fit in LDS");
     if (lds > 48 * 1024) DH_MAX_LDS_ONCE((gemm_skinny_rows_kernel<KPS, NG, NGL, CT>), lds);
     dim3 grid(cdiv(N, 128 * CT), ksplit, cdiv(M, NG * 32)), block(512);
     hipLaunchKernelGGL((gemm_skinny_rows_kernel<KPS, NG, NGL, CT>), grid, block, lds, s, x, w, w_ext, y32, M, n_main, N, K);
@@ -431,7 +481,7 @@ extern "C" int dh_linear_partial_bf16(const dh_bf16* x, const dh_bf16* w, const 
     const int kps = (nks + ksplit - 1) / ksplit;
     hipStream_t s = (hipStream_t)stream;
     // the kernel is a function of (K, ksplit) alone, never of M: rows of a larger call equal the same rows alone
-    if (g_skinny_variant == 1 && (kps == 8 || kps == 16) && (ksplit - 1) * kps < nks && N % 4 == 0 && K % 64 == 0) {
+    if (g_skinny_variant == 1 && (kps == 8 || kps == 16) && ksplit * kps == nks && N % 4 == 0) {
         if (kps == 8) return launch_rows_ng<8>(x, w, w_ext ? w_ext : w, y32, M, n_main, N, K, ksplit, s);
         return launch_rows_ng<16>(x, w, w_ext ? w_ext : w, y32, M, n_main, N, K, ksplit, s);
     }
