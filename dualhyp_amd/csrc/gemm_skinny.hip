@@ -271,6 +271,11 @@ __global__ __launch_bounds__(512, 2) void gemm_skinny_partial_kernel(const bf16_
 // LDS port, not the weight stream, bounds the kernel (rocprof at 640 rows: 275-316 TFLOP/s); with CT tiles one x
 // fragment feeds CT MFMAs.  The summation order is untouched: same K-slices, same chain inside a slice.
 //   grid (ceil(N/(128*CT)), ksplit, ceil(M / (32*NG))), K-slice = KPS k-steps of 32.
+#ifdef DH_ROWS_NT_STORE
+#define PSTORE(p, v) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p))
+#else
+#define PSTORE(p, v) (*reinterpret_cast<f32x4*>(p) = (v))
+#endif
 #ifdef DH_ROWS_STAMPS   // diagnostic build only (tools/probe_rows.py): 100 MHz timestamps of wave 0 per block
 __device__ unsigned long long g_rows_stamps[1024 * 8];
 #define ROWS_STAMP(i) do { if (threadIdx.x == 0) { const int _b = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
@@ -393,8 +398,8 @@ __global__ __launch_bounds__(512, NG == 1 ? 2 : 1) void gemm_skinny_rows_kernel(
                         f32x4 r0, r1;
                         tiles_to_lines(h ? acc_hi[g][cp] : acc_lo[g][cp], h ? acc_hi[g][cp + 1] : acc_lo[g][cp + 1], lidx, r0, r1);
                         const int m_a = mg + h * 16 + (lane >> 3), m_b = m_a + 8;
-                        if (m_a < M) *reinterpret_cast<f32x4*>(o + (size_t)m_a * N) = r0;
-                        if (m_b < M) *reinterpret_cast<f32x4*>(o + (size_t)m_b * N) = r1;
+                        if (m_a < M) PSTORE(o + (size_t)m_a * N, r0);
+                        if (m_b < M) PSTORE(o + (size_t)m_b * N, r1);
                     }
                 }
             } else {
