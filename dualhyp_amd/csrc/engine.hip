@@ -26,6 +26,7 @@ constexpr int MAX_DECODE_ROWS = 2048;  // single-token calls up to here take the
 // k order) instead of the K-sliced streaming kernels: from a few hundred rows on the step is no longer weight-
 // bandwidth-bound and the partial-sum traffic of the K slices dominates (dh_set_tuning key 10; 0 = never).
 int g_decode_tiled_rows = 0;
+int g_short_kps = 8;       // k-steps per K-slice of the partial-sum GEMMs when K <= 4096 (dh_set_tuning key 16: 8 or 16)
 int g_fuse_qkv_rope = 1;   // dh_set_tuning key 12: 0 = QKV GEMM, then dh_qkv_rope_cache_bf16 (the two-step form)
 
 struct dh_engine {
@@ -290,7 +291,7 @@ int head_fp8(dh_engine* e, const bf16_t* xrows, int rows, bf16_t* logits, const 
 // K-slices of 8 (or 16 for long K) k-steps: the row-parallel streaming kernel (gemm_skinny.hip)
 int pick_ksplit(int tiles, int nks) {
     (void)tiles;
-    if (nks <= 128) return (nks + 7) / 8;
+    if (nks <= 128) return g_short_kps == 16 && nks % 16 == 0 ? nks / 16 : (nks + 7) / 8;
     if (nks <= 256) return (nks + 15) / 16;
     int ks = 1;
     while (ks < 4 && nks / (16 * ks) >= 2) ks *= 2;

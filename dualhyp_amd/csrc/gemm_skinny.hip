@@ -534,6 +534,7 @@ extern "C" int dh_set_tuning(int key, int value) {
     if (key == 11 && value >= 0) { g_rows_ct = value; return 0; }
     if (key == 12) { extern int g_fuse_qkv_rope; g_fuse_qkv_rope = value; return 0; }
     if (key == 14 && (value == 0 || value == 8 || value == 10)) { g_rows_ng = value; return 0; }
+    if (key == 16 && (value == 8 || value == 16)) { extern int g_short_kps; g_short_kps = value; return 0; }
     if (key == 15) { extern int g_dt_wide; g_dt_wide = value; return 0; }
     if (key == 13) { extern int g_mid_wlds; g_mid_wlds = value; return 0; }
     dh_set_error("dh_set_tuning: unknown key %d", key);
