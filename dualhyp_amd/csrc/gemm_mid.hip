@@ -119,18 +119,8 @@ __global__ __launch_bounds__(640) void gemm_mid_kernel(GemmArgs a) {
     const int n0 = blockIdx.x * (16 * RS) + rs * 16;
     int n = n0 + lrow;
     n = n < a.N ? n : a.N - 1;
-#if defined(DH_MID_WSHAPE) && DH_MID_WSHAPE == 1      // timing experiment (wrong results): same bytes per instruction, lane-sorted
-    const int nx = min(n0 + (lane >> 2), a.N - 1);
-    const bf16_t* w1 = a.w + (size_t)nx * a.K + (lane & 3) * 8;
-    const bf16_t* w2 = SW ? a.w2 + (size_t)nx * a.K + (lane & 3) * 8 : nullptr;
-#elif defined(DH_MID_WSHAPE) && DH_MID_WSHAPE == 2    // timing experiment (wrong results): 8 rows x 128 B per instruction
-    const int nx = min(n0 + (lane >> 3), a.N - 1);
-    const bf16_t* w1 = a.w + (size_t)nx * a.K + (lane & 7) * 8;
-    const bf16_t* w2 = SW ? a.w2 + (size_t)nx * a.K + (lane & 7) * 8 : nullptr;
-#else
     const bf16_t* w1 = a.w + (size_t)n * a.K + kg * 8;
     const bf16_t* w2 = SW ? a.w2 + (size_t)n * a.K + kg * 8 : nullptr;
-#endif
 
     f32x4 acc[NI];
 #pragma unroll
@@ -215,11 +205,7 @@ __global__ __launch_bounds__(640) void gemm_mid_kernel(GemmArgs a) {
         auto load_w = [&](bf16x8 (&wf)[NM][KPW], int s) __attribute__((always_inline)) {
 #pragma unroll
             for (int c = 0; c < KPW; ++c) {
-#if defined(DH_MID_WSHAPE) && DH_MID_WSHAPE == 2
-                const int ko = (kq * kpart + ((s * KPW + c) & ~1)) * 32 + ((s * KPW + c) & 1) * 8 * a.K;
-#else
                 const int ko = (kq * kpart + s * KPW + c) * 32;
-#endif
                 wf[0][c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(w1 + ko));
                 if (SW) wf[NM - 1][c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(w2 + ko));
             }
