@@ -26,7 +26,9 @@ namespace {
 // ------------------------------------------------------------------------------------ prefill
 // grid (q tiles of 32, n_groups, n_seq); block = 64 * q_per_kv threads: one wave per query head
 // of the group, all waves share the K / V^T tiles of 64 keys staged in LDS.
-template <int HS>
+// PS: scale is a power of two (head size 64: 1/8), so it is applied to the Q fragments once — exact in bf16 and in the
+// fp32 products and sums (barring underflow) — instead of to every score: the loop is bound by its softmax VALU work.
+template <int HS, bool PS = false>
 __global__ __launch_bounds__(HS == 64 ? 1024 : 512) void attn_prefill_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k_cache, const bf16_t* __restrict__ vT_cache,
     const int32_t* __restrict__ seq_slot, const int32_t* __restrict__ q_start, const int32_t* __restrict__ q_len,
@@ -58,6 +60,12 @@ __global__ __launch_bounds__(HS == 64 ? 1024 : 512) void attn_prefill_kernel(
         const bf16_t* qp = q + ((size_t)(qs + row) * n_head + head) * HS + lh * 8;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+        if (PS) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) qf[ks][e] = (short)f2bf(bf2f((bf16_t)qf[ks][e]) * scale);
+        }
     }
 
     f32x16 o[DT];
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(HS == 64 ? 1024 : 512) void attn_prefill_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key_abs = key0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float s = st[rt][r] * scale;
+                float s = PS ? st[rt][r] : st[rt][r] * scale;
                 s = key_abs <= q_abs ? s : -INFINITY;
                 st[rt][r] = s;
                 m_t = fmaxf(m_t, s);
@@ -133,10 +141,12 @@ __global__ __launch_bounds__(HS == 64 ? 1024 : 512) void attn_prefill_kernel(
                 psum += p;
             }
         l_run = l_run * alpha + psum;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {   // the running max moved for some query of the wave
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+            for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        }
 
         // ---- O^T += V^T · P^T
 #pragma unroll
@@ -329,7 +339,7 @@ extern "C" int dh_attn_prefill_bf16(const dh_bf16* q, const dh_bf16* k_cache, co
     const float scale = 1.0f / sqrtf((float)hs);
     hipStream_t s = (hipStream_t)stream;
     if (hs == 64)
-        hipLaunchKernelGGL((attn_prefill_kernel<64>), grid, block, 0, s, q, k_cache, vT_cache, seq_slot, q_start, q_len,
+        hipLaunchKernelGGL((attn_prefill_kernel<64, true>), grid, block, 0, s, q, k_cache, vT_cache, seq_slot, q_start, q_len,   // scale = 1/8
                            kv_pos0, y, lse, n_head, n_groups, s_max, scale);
     else
         hipLaunchKernelGGL((attn_prefill_kernel<128>), grid, block, 0, s, q, k_cache, vT_cache, seq_slot, q_start, q_len,
