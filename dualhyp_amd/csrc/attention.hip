@@ -115,18 +115,27 @@ __global__ __launch_bounds__(HS == 64 ? 1024 : 512) void attn_prefill_kernel(
                 st[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st[rt], 0, 0, 0);
             }
         }
-        // ---- scale, causal mask, tile max
+        // ---- scale, causal mask (only a tile that reaches past the block's first query can hold masked keys), tile max
+        if (!PS) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st[rt][r] *= scale;
+        }
+        if (key0 + 63 > p0) {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key_abs = key0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    st[rt][r] = key_abs <= q_abs ? st[rt][r] : -INFINITY;
+                }
+        }
         float m_t = -INFINITY;
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key_abs = key0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float s = PS ? st[rt][r] : st[rt][r] * scale;
-                s = key_abs <= q_abs ? s : -INFINITY;
-                st[rt][r] = s;
-                m_t = fmaxf(m_t, s);
-            }
+            for (int r = 0; r < 16; ++r) m_t = fmaxf(m_t, st[rt][r]);
         m_t = fmaxf(m_t, __shfl_xor(m_t, 32, 64));
         const float m_new = fmaxf(m_run, m_t);           // finite: key 0 is always visible
         const float alpha = __expf(m_run - m_new);
