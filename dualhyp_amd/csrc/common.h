@@ -41,6 +41,19 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// silu(g) = g / (1 + e^-g) for the PREFILL GEMM epilogues (both tile sizes, so rows stay tile-size invariant): hardware
+// exp2 and reciprocal (about 1 ulp each; the argument product adds |g| * 1e-7 relative).  libm's expf and the IEEE
+// division cost ~45 VALU instructions per element, 64 elements per lane: 5.8 us of a 60-us SwiGLU tile
+// (tools/probe_gemm256.py).  The value is rounded to bf16 right after: a relative error of a few 1e-7 moves about one
+// result in 10^4 by one bf16 ulp, as libm-vs-Sleef differences between the reference's CPU and GPU runs do.
+__device__ __forceinline__ float silu_fast(float g) {
+#ifdef DH_SILU_EXACT   // A/B builds only
+    return g / (1.0f + expf(-g));
+#else
+    return g * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-g * 1.44269504088896341f));
+#endif
+}
+
 // ---- async global -> LDS, 16 B per lane; LDS destination = wave-uniform base + lane*16 ----
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,

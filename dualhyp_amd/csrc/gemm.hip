@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs a) {
                 for (int e = 0; e < 4; ++e) {
                     const float g = rbf(acc[i][j][e]);
                     const float u = rbf(acc[i + 2][j][e]);
-                    const float sg = rbf(g / (1.0f + expf(-g)));
+                    const float sg = rbf(silu_fast(g));
                     o[e] = sg * u;
                 }
                 if (m_ok && n < a.N) {

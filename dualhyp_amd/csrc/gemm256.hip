@@ -26,9 +26,20 @@ constexpr int BT2 = 256;
 constexpr int BK = 64;
 constexpr int TILE_B = BT2 * BK * 2;   // 32 KiB
 
+#ifdef DH_G256_STAMPS   // diagnostic build only (tools/probe_gemm256.py): 100 MHz timestamps of wave 0 per block
+__device__ unsigned long long g_g256_stamps[8192 * 4];
+#define G256_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_g256_stamps[blockIdx.x * 4 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int dh_debug_g256_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_g256_stamps), sizeof(g_g256_stamps)) == hipSuccess ? 0 : 1;
+}
+#else
+#define G256_STAMP(i)
+#endif
+
 template <int EPI, bool RESID, int PIPE>
 __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    G256_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 2, wm = wave & 3;
     const int frow = lane & 15, kg = lane >> 4;
@@ -206,6 +217,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
         if (2 < nks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        G256_STAMP(1);
         bf16x8 faA[8], fbA[4], faB[8], fbB[4];
         if constexpr (PIPE == 1) {
         load_frags(0, faA, fbA);
@@ -272,6 +284,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
         }
     }
 
+    G256_STAMP(2);
     // ---------------------------------------------------------------- epilogue
     // acc[i][j][r]: n = nt + 4*kg + r , m = mt + frow: a lane holds 4 consecutive n (8 bytes of bf16) of one
     // row; the four kg lanes of a row hold one 16-column tile.  Tiles are finished in PAIRS and one
@@ -420,7 +433,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
                 for (int e = 0; e < 4; ++e) {
                     const float g = rbf(acc[i][j][e]);
                     const float u = rbf(acc[i + 4][j][e]);
-                    o[e] = rbf(g / (1.0f + expf(-g))) * u;
+                    o[e] = rbf(silu_fast(g)) * u;
                 }
             } else {
 #pragma unroll
@@ -474,6 +487,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
             }
         }
     }
+    G256_STAMP(3);
 }
 
 template <int EPI, bool RESID, int PIPE>

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Per-tile timeline of the 256-tile prefill GEMM from a -DDH_G256_STAMPS build (DUALHYP_HIP_LIB=tools/bin/libG.so):
+launch -> first stage in LDS -> main loop done -> epilogue stores issued.  Wave 0 stamps; the stores drain after the
+last stamp, so the gap to the NEXT tile's start on the same CU is part of the epilogue's real cost.  GPU box."""
+import ctypes, sys
+from pathlib import Path
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import numpy as np, torch
+from dualhyp_amd import ops, _lib
+lib = _lib.load()
+raw = ctypes.CDLL(str(_lib.LIB_PATH))
+D = "cuda:0"
+M, d, I = 2 * 32 * 512, 2048, 5632
+g = torch.Generator(device=D).manual_seed(0)
+rn = lambda *s: (torch.randn(*s, device=D, generator=g) * 0.05).bfloat16()
+x, act = rn(M, d), rn(M, I)
+W1, W2, Wm = rn(I, d), rn(I, d), rn(d, I)
+def stamps(n):
+    buf = np.zeros(8192 * 4, dtype=np.uint64)
+    assert raw.dh_debug_g256_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+    return buf.reshape(8192, 4)[:n].astype(np.int64)
+for (nm, fn, nblk) in (("SwiGLU (K 2048)", lambda: ops.linear(x, W1, epilogue=ops.EPI_SWIGLU, w2=W2), 128 * 44),
+                       ("mlp proj + residual (K 5632)", lambda: ops.linear(act, Wm, resid=x), 128 * 8)):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    st = stamps(nblk)
+    t0 = st[:, 0].min()
+    seg = np.stack([st[:, 1] - st[:, 0], st[:, 2] - st[:, 1], st[:, 3] - st[:, 2], st[:, 3] - st[:, 0]], 1) * 0.01
+    print(f"{nm}: {nblk} tiles, kernel span {(st[:, 3].max() - t0) * 0.01:.1f} us")
+    for j, n in enumerate(["launch -> first stage landed", "main loop", "epilogue (to last store issued)", "whole tile"]):
+        v = seg[:, j]
+        print(f"   {n:32s} median {np.median(v):6.2f}  p10 {np.percentile(v, 10):6.2f}  p90 {np.percentile(v, 90):6.2f} us")
+    # gap between consecutive tiles on the same CU cannot be read from block ids; estimate from occupancy:
+    busy = seg[:, 3].sum() / 256
+    print(f"   sum of tile times / 256 CUs = {busy:.1f} us of the {(st[:, 3].max() - t0) * 0.01:.1f} us span")
