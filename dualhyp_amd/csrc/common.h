@@ -41,7 +41,8 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// silu(g) = g / (1 + e^-g) for the PREFILL GEMM epilogues (both tile sizes, so rows stay tile-size invariant): hardware
+// silu(g) = g / (1 + e^-g) for every SwiGLU epilogue (prefill tiles of both sizes, the decode family, fp8, the training
+// forward: one formula, so no row depends on which kernel finished it): hardware
 // exp2 and reciprocal (about 1 ulp each; the argument product adds |g| * 1e-7 relative).  libm's expf and the IEEE
 // division cost ~45 VALU instructions per element, 64 elements per lane: 5.8 us of a 60-us SwiGLU tile
 // (tools/probe_gemm256.py).  The value is rounded to bf16 right after: a relative error of a few 1e-7 moves about one

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(Fp8Args a) {
                 for (int e = 0; e < 4; ++e) {
                     const float g = rbf(acc[i][j][e] * (xs * s1p[e]));
                     const float u = rbf(acc[i + 2][j][e] * (xs * s2p[e]));
-                    o[e] = rbf(g / (1.0f + expf(-g))) * u;
+                    o[e] = rbf(silu_fast(g)) * u;
                 }
                 *reinterpret_cast<uint2*>(a.y + (size_t)m * a.N + n) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
             }
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_skinny_kernel(Fp8Args a) {
             }
             gt = rbf(gt * (xs * a.ws[nn]));
             u = rbf(u * (xs * a.ws2[nn]));
-            o = rbf(gt / (1.0f + expf(-gt))) * u;
+            o = rbf(silu_fast(gt)) * u;
         } else {
             float s = 0.f;
 #pragma unroll

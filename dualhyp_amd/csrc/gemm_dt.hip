@@ -189,7 +189,7 @@ __global__ __launch_bounds__(WN * 128) void gemm_dt_kernel(DtArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float gt = rbf(tot[i][j][r]), up = rbf(tot[i + 2][j][r]);
-                    o[r] = rbf(gt / (1.0f + expf(-gt))) * up;
+                    o[r] = rbf(silu_fast(gt)) * up;
                 }
                 *reinterpret_cast<uint2*>((bf16_t*)a.y + (size_t)m * a.N + n) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
             }

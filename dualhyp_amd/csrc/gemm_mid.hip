@@ -292,7 +292,7 @@ __global__ __launch_bounds__(640) void gemm_mid_kernel(GemmArgs a) {
         for (int r = 0; r < 4; ++r) {
             if (SW) {
                 const float gt = rbf(tot[0][r]), up = rbf(tot[NM - 1][r]);
-                o[r] = rbf(gt / (1.0f + expf(-gt))) * up;
+                o[r] = rbf(silu_fast(gt)) * up;
             } else {
                 o[r] = rbf(tot[0][r]);
                 if (EPI == DH_EPI_ADAPTER) o[r] = rbf(va[r] * rbf(o[r] + vb[r]));

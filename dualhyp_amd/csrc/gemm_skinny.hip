@@ -94,7 +94,7 @@ __global__ __launch_bounds__(512, 2) void gemm_skinny_kernel(GemmArgs a) {
         }
         g = rbf(g);
         u = rbf(u);
-        o = rbf(g / (1.0f + expf(-g))) * u;
+        o = rbf(silu_fast(g)) * u;
     } else {
         float s = 0.f;
 #pragma unroll
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(512, 1) void swiglu_skinny2_kernel(GemmArgs a) {
         }
         g = rbf(g);
         u = rbf(u);
-        a.y[(size_t)tm * a.N + nn] = f2bf(rbf(g / (1.0f + expf(-g))) * u);
+        a.y[(size_t)tm * a.N + nn] = f2bf(rbf(silu_fast(g)) * u);
     }
 }
 

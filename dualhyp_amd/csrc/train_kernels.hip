@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restric
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float gg = bf2f(gp[e]);
-            op[e] = f2bf(rbf(gg / (1.0f + expf(-gg))) * bf2f(up[e]));
+            op[e] = f2bf(rbf(silu_fast(gg)) * bf2f(up[e]));
         }
         reinterpret_cast<uint4*>(act)[c] = o;
     }
