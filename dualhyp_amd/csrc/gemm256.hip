@@ -45,245 +45,28 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
     const int frow = lane & 15, kg = lane >> 4;
 
     const int nwg = a.nb_n * a.nb_m;
-    int tile;
-    {
-        const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
     // tiles are walked in bands of `gm` m-tiles, m fastest: the ~32 blocks an XCD runs at a time then form a
     // gm x (32/gm) rectangle that shares gm x-tile streams and 32/gm W-tile streams through its L2
     // instead of 1 + 32 (row-major); a.gm = 1 is the row-major order
-    int tm, tn;
-    {
+    auto tile_origin = [&](int bid, int& m0, int& n0) __attribute__((always_inline)) {
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
         const int gm = a.gm, band = tile / (gm * a.nb_n), within = tile - band * (gm * a.nb_n);
         const int rows = min(gm, a.nb_m - band * gm);
-        tm = band * gm + within % rows;
-        tn = within / rows;
-    }
-    const int m0 = tm * BT2;
-    const int n0 = (EPI == DH_EPI_SWIGLU) ? tn * 128 : tn * BT2;
+        const int tm = band * gm + within % rows, tn = within / rows;
+        m0 = tm * BT2;
+        n0 = (EPI == DH_EPI_SWIGLU) ? tn * 128 : tn * BT2;
+    };
+    int m0, n0;
+    tile_origin(blockIdx.x, m0, n0);
+    // PIPE 3: PERSISTENT ping-pong — the grid is one block per CU and a block walks tiles bid, bid + grid, ...; the first
+    // three stages of the NEXT tile are requested before the epilogue of the current one, so the epilogue (2.8-10.8 us),
+    // the store drain, the block dispatch and the first-stage latency (2 us) of tools/probe_gemm256.py's timeline overlap
+    constexpr bool PERSIST = PIPE == 3;
+    constexpr int LOOP = PIPE == 3 ? 2 : PIPE;
 
     f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    if constexpr (PIPE == 0) {
-    // ---- staging sources: 4 (W) + 4 (x) one-KiB row groups per wave and K-tile
-    const bf16_t* srcA[4];
-    const bf16_t* srcB[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int R = wave * 4 + j;
-        const int row = R * 8 + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-        {
-            const bf16_t* base = a.w;
-            int n;
-            if (EPI == DH_EPI_SWIGLU) {
-                // wave-row half wn holds 64 rows of fc_1 followed by the same 64 rows of fc_2
-                const int within = row & 127;
-                n = n0 + (row >> 7) * 64 + (within & 63);
-                base = within >= 64 ? a.w2 : a.w;
-            } else {
-                n = n0 + row;
-            }
-            n = n < a.N ? n : a.N - 1;
-            srcA[j] = base + (size_t)n * a.K + chunk * 8;
-        }
-        {
-            int m = m0 + row;
-            m = m < a.M ? m : a.M - 1;
-            srcB[j] = a.x + (size_t)m * a.K + chunk * 8;
-        }
-    }
-    auto stage = [&](int buf, int kt) {
-        char* sA = smem + buf * 2 * TILE_B;
-        char* sB = sA + TILE_B;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int R = wave * 4 + j;
-            glds16(srcA[j] + kt * BK, sA + R * 1024);
-            glds16(srcB[j] + kt * BK, sB + R * 1024);
-        }
-    };
-
-    const int sw = (frow >> 1) & 7;
-    const int offA = (wn * 128 + frow) * 128, offB = (wm * 64 + frow) * 128;
-
-    const int nk = a.K / BK;
-    stage(0, 0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-        const char* sA = smem + cur * 2 * TILE_B;
-        const char* sB = sA + TILE_B;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int co = ((ks * 4 + kg) ^ sw) << 4;
-            bf16x8 fb[4], fa[8];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(sB + offB + j * 2048 + co);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sA + offA + i * 2048 + co);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-        }
-        __syncthreads();
-    }
-
-    } else {
-        // ---- deep pipeline: a stage is ONE 32-deep k-step (W 16 KiB + x 16 KiB), four stages in LDS.
-        // Steady state of iteration k:  ds_read frags(k+1) | global_load_lds stage k+3 | 32 MFMA on
-        // frags(k) | s_waitcnt vmcnt(4) (stage k+2 has landed, k+3 stays in flight) | s_barrier.
-        // Fragment reads and DMA issue sit in front of the MFMA block they overlap with; nothing
-        // drains to vmcnt(0) inside the loop (cdna_hip_programming.md T3+T4).
-        constexpr int STG = 2 * 256 * 64;               // bytes per stage (A then B), rows of 64 B
-        const bf16_t* srcA[2];
-        const bf16_t* srcB[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int R = wave * 2 + j;                   // 1-KiB group = 16 rows of 64 B
-            const int row = R * 16 + (lane >> 2);
-            const int chunk = (lane & 3) ^ ((row >> 1) & 3);
-            {
-                const bf16_t* base = a.w;
-                int n;
-                if (EPI == DH_EPI_SWIGLU) {
-                    const int within = row & 127;
-                    n = n0 + (row >> 7) * 64 + (within & 63);
-                    base = within >= 64 ? a.w2 : a.w;
-                } else {
-                    n = n0 + row;
-                }
-                n = n < a.N ? n : a.N - 1;
-                srcA[j] = base + (size_t)n * a.K + chunk * 8;
-            }
-            {
-                int m = m0 + row;
-                m = m < a.M ? m : a.M - 1;
-                srcB[j] = a.x + (size_t)m * a.K + chunk * 8;
-            }
-        }
-        auto stage = [&](int ks) {
-            char* sA = smem + (ks & 3) * STG;
-            char* sB = sA + STG / 2;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int R = wave * 2 + j;
-                glds16(srcA[j] + ks * 32, sA + R * 1024);
-                glds16(srcB[j] + ks * 32, sB + R * 1024);
-            }
-        };
-        const int co = (kg ^ ((frow >> 1) & 3)) << 4;
-        const int offA = (wn * 128 + frow) * 64 + co, offB = (wm * 64 + frow) * 64 + co;
-        auto load_frags = [&](int ks, bf16x8 (&fa)[8], bf16x8 (&fb)[4]) {
-            const char* sA = smem + (ks & 3) * STG;
-            const char* sB = sA + STG / 2;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(sB + offB + j * 1024);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sA + offA + i * 1024);
-        };
-        // first row of MFMAs (needs only the fragments read one step ago: the compiler's wait at this
-        // point covers nothing newer), then the NEXT step's 12 ds_read_b128, then the other 28 MFMAs
-        auto mma_head = [&](const bf16x8 (&fa)[8], const bf16x8 (&fb)[4]) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[j], acc[0][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        auto mma_tail = [&](const bf16x8 (&fa)[8], const bf16x8 (&fb)[4]) {
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 1; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-        };
-        const int nks = a.K / 32;                         // even: K % 64 == 0
-        stage(0);
-        stage(1);
-        if (2 < nks) stage(2);
-        if (2 < nks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        G256_STAMP(1);
-        bf16x8 faA[8], fbA[4], faB[8], fbB[4];
-        if constexpr (PIPE == 1) {
-        load_frags(0, faA, fbA);
-        for (int k = 0; k < nks; k += 2) {
-            // ---- even step: compute frags A (k), prefetch frags B (k+1)
-            if (k + 3 < nks) stage(k + 3);
-            mma_head(faA, fbA);
-            load_frags(k + 1, faB, fbB);
-            mma_tail(faA, fbA);
-            if (k + 3 < nks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            // ---- odd step: compute frags B (k+1), prefetch frags A (k+2)
-            if (k + 4 < nks) stage(k + 4);
-            mma_head(faB, fbB);
-            if (k + 2 < nks) load_frags(k + 2, faA, fbA);
-            mma_tail(faB, fbB);
-            if (k + 4 < nks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-        } else {
-        // ---- ping-pong: the two waves of a SIMD (wave w and w+4, i.e. the two wn halves) run half a
-        // step apart, so while one owns the MFMA pipe (compute slot: 32 MFMAs on the fragments it
-        // holds) the other is in its memory slot (DMA request for stage k+3, 12 ds_read_b128 of the
-        // NEXT step's fragments, wait for its share of stage k+2).  Every slot ends with s_barrier; the
-        // wn = 1 waves take one extra barrier up front and the wn = 0 waves one at the end.
-        //   slot 2k   : wn0 C(k)   | wn1 M(k-1)
-        //   slot 2k+1 : wn0 M(k)   | wn1 C(k)
-        // Stage k+3 overwrites the buffer of step k-1, whose fragments were read in M(k-2) (>= 3 slots
-        // earlier for either half); fragments of step k+1 are read in M(k), after both halves' shares
-        // of stage k+1 were waited for in their M(k-1) (>= 1 barrier earlier).
-        auto compute = [&](const bf16x8 (&fa)[8], const bf16x8 (&fb)[4]) __attribute__((always_inline)) {
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        auto memory = [&](int k, bf16x8 (&fa)[8], bf16x8 (&fb)[4]) __attribute__((always_inline)) {
-            if (k + 3 < nks) stage(k + 3);
-            if (k + 1 < nks) load_frags(k + 1, fa, fb);
-            if (k + 3 < nks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        load_frags(0, faA, fbA);
-        if (wn == 1) __builtin_amdgcn_s_barrier();
-        for (int k = 0; k < nks; k += 2) {
-            compute(faA, fbA);
-            memory(k, faB, fbB);
-            compute(faB, fbB);
-            memory(k + 1, faA, fbA);
-        }
-        if (wn == 0) __builtin_amdgcn_s_barrier();
-        }
-    }
-
+    auto epilogue = [&](const int m0, const int n0) __attribute__((always_inline)) {
     G256_STAMP(2);
     // ---------------------------------------------------------------- epilogue
     // acc[i][j][r]: n = nt + 4*kg + r , m = mt + frow: a lane holds 4 consecutive n (8 bytes of bf16) of one
@@ -488,13 +271,271 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
         }
     }
     G256_STAMP(3);
+    };
+    auto zero_acc = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    zero_acc();
+
+    if constexpr (LOOP == 0) {
+    // ---- staging sources: 4 (W) + 4 (x) one-KiB row groups per wave and K-tile
+    const bf16_t* srcA[4];
+    const bf16_t* srcB[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int R = wave * 4 + j;
+        const int row = R * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        {
+            const bf16_t* base = a.w;
+            int n;
+            if (EPI == DH_EPI_SWIGLU) {
+                // wave-row half wn holds 64 rows of fc_1 followed by the same 64 rows of fc_2
+                const int within = row & 127;
+                n = n0 + (row >> 7) * 64 + (within & 63);
+                base = within >= 64 ? a.w2 : a.w;
+            } else {
+                n = n0 + row;
+            }
+            n = n < a.N ? n : a.N - 1;
+            srcA[j] = base + (size_t)n * a.K + chunk * 8;
+        }
+        {
+            int m = m0 + row;
+            m = m < a.M ? m : a.M - 1;
+            srcB[j] = a.x + (size_t)m * a.K + chunk * 8;
+        }
+    }
+    auto stage = [&](int buf, int kt) {
+        char* sA = smem + buf * 2 * TILE_B;
+        char* sB = sA + TILE_B;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int R = wave * 4 + j;
+            glds16(srcA[j] + kt * BK, sA + R * 1024);
+            glds16(srcB[j] + kt * BK, sB + R * 1024);
+        }
+    };
+
+    const int sw = (frow >> 1) & 7;
+    const int offA = (wn * 128 + frow) * 128, offB = (wm * 64 + frow) * 128;
+
+    const int nk = a.K / BK;
+    stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+        const char* sA = smem + cur * 2 * TILE_B;
+        const char* sB = sA + TILE_B;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int co = ((ks * 4 + kg) ^ sw) << 4;
+            bf16x8 fb[4], fa[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(sB + offB + j * 2048 + co);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sA + offA + i * 2048 + co);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        __syncthreads();
+    }
+    epilogue(m0, n0);
+
+    } else {
+        // ---- deep pipeline: a stage is ONE 32-deep k-step (W 16 KiB + x 16 KiB), four stages in LDS.
+        // Steady state of iteration k:  ds_read frags(k+1) | global_load_lds stage k+3 | 32 MFMA on
+        // frags(k) | s_waitcnt vmcnt(4) (stage k+2 has landed, k+3 stays in flight) | s_barrier.
+        // Fragment reads and DMA issue sit in front of the MFMA block they overlap with; nothing
+        // drains to vmcnt(0) inside the loop (cdna_hip_programming.md T3+T4).
+        constexpr int STG = 2 * 256 * 64;               // bytes per stage (A then B), rows of 64 B
+        const bf16_t* srcA[2];
+        const bf16_t* srcB[2];
+        auto setup_src = [&](const int m0, const int n0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int R = wave * 2 + j;                   // 1-KiB group = 16 rows of 64 B
+            const int row = R * 16 + (lane >> 2);
+            const int chunk = (lane & 3) ^ ((row >> 1) & 3);
+            {
+                const bf16_t* base = a.w;
+                int n;
+                if (EPI == DH_EPI_SWIGLU) {
+                    const int within = row & 127;
+                    n = n0 + (row >> 7) * 64 + (within & 63);
+                    base = within >= 64 ? a.w2 : a.w;
+                } else {
+                    n = n0 + row;
+                }
+                n = n < a.N ? n : a.N - 1;
+                srcA[j] = base + (size_t)n * a.K + chunk * 8;
+            }
+            {
+                int m = m0 + row;
+                m = m < a.M ? m : a.M - 1;
+                srcB[j] = a.x + (size_t)m * a.K + chunk * 8;
+            }
+        }
+        };
+        setup_src(m0, n0);
+        auto stage = [&](int ks) {
+            char* sA = smem + (ks & 3) * STG;
+            char* sB = sA + STG / 2;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int R = wave * 2 + j;
+                glds16(srcA[j] + ks * 32, sA + R * 1024);
+                glds16(srcB[j] + ks * 32, sB + R * 1024);
+            }
+        };
+        const int co = (kg ^ ((frow >> 1) & 3)) << 4;
+        const int offA = (wn * 128 + frow) * 64 + co, offB = (wm * 64 + frow) * 64 + co;
+        auto load_frags = [&](int ks, bf16x8 (&fa)[8], bf16x8 (&fb)[4]) {
+            const char* sA = smem + (ks & 3) * STG;
+            const char* sB = sA + STG / 2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(sB + offB + j * 1024);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sA + offA + i * 1024);
+        };
+        // first row of MFMAs (needs only the fragments read one step ago: the compiler's wait at this
+        // point covers nothing newer), then the NEXT step's 12 ds_read_b128, then the other 28 MFMAs
+        auto mma_head = [&](const bf16x8 (&fa)[8], const bf16x8 (&fb)[4]) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[0][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0], fb[j], acc[0][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto mma_tail = [&](const bf16x8 (&fa)[8], const bf16x8 (&fb)[4]) {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 1; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        const int nks = a.K / 32;                         // even: K % 64 == 0
+        stage(0);
+        stage(1);
+        if (2 < nks) stage(2);
+        for (int vb = blockIdx.x;;) {
+        if (2 < nks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // (PERSIST: also the previous tile's stores — loads and
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          //  stores share the counter; at most 4 LOADS stay out)
+        __builtin_amdgcn_s_barrier();
+        G256_STAMP(1);
+        bf16x8 faA[8], fbA[4], faB[8], fbB[4];
+        if constexpr (LOOP == 1) {
+        load_frags(0, faA, fbA);
+        for (int k = 0; k < nks; k += 2) {
+            // ---- even step: compute frags A (k), prefetch frags B (k+1)
+            if (k + 3 < nks) stage(k + 3);
+            mma_head(faA, fbA);
+            load_frags(k + 1, faB, fbB);
+            mma_tail(faA, fbA);
+            if (k + 3 < nks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            // ---- odd step: compute frags B (k+1), prefetch frags A (k+2)
+            if (k + 4 < nks) stage(k + 4);
+            mma_head(faB, fbB);
+            if (k + 2 < nks) load_frags(k + 2, faA, fbA);
+            mma_tail(faB, fbB);
+            if (k + 4 < nks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        } else {
+        // ---- ping-pong: the two waves of a SIMD (wave w and w+4, i.e. the two wn halves) run half a
+        // step apart, so while one owns the MFMA pipe (compute slot: 32 MFMAs on the fragments it
+        // holds) the other is in its memory slot (DMA request for stage k+3, 12 ds_read_b128 of the
+        // NEXT step's fragments, wait for its share of stage k+2).  Every slot ends with s_barrier; the
+        // wn = 1 waves take one extra barrier up front and the wn = 0 waves one at the end.
+        //   slot 2k   : wn0 C(k)   | wn1 M(k-1)
+        //   slot 2k+1 : wn0 M(k)   | wn1 C(k)
+        // Stage k+3 overwrites the buffer of step k-1, whose fragments were read in M(k-2) (>= 3 slots
+        // earlier for either half); fragments of step k+1 are read in M(k), after both halves' shares
+        // of stage k+1 were waited for in their M(k-1) (>= 1 barrier earlier).
+        auto compute = [&](const bf16x8 (&fa)[8], const bf16x8 (&fb)[4]) __attribute__((always_inline)) {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto memory = [&](int k, bf16x8 (&fa)[8], bf16x8 (&fb)[4]) __attribute__((always_inline)) {
+            if (k + 3 < nks) stage(k + 3);
+            if (k + 1 < nks) load_frags(k + 1, fa, fb);
+            if (k + 3 < nks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        load_frags(0, faA, fbA);
+        if (wn == 1) __builtin_amdgcn_s_barrier();
+        for (int k = 0; k < nks; k += 2) {
+            compute(faA, fbA);
+            memory(k, faB, fbB);
+            compute(faB, fbB);
+            memory(k + 1, faA, fbA);
+        }
+        if (wn == 0) __builtin_amdgcn_s_barrier();
+        }
+        // every fragment of this tile has been read (the loop ends with a barrier): the ring is free for the next tile
+        const int vb_next = vb + (int)gridDim.x;
+        const bool more = PERSIST && vb_next < nwg;
+        int m0n = 0, n0n = 0;
+        if (more) {
+            tile_origin(vb_next, m0n, n0n);
+            setup_src(m0n, n0n);
+            stage(0);
+            stage(1);
+            if (2 < nks) stage(2);
+        }
+        epilogue(m0, n0);
+        if (!more) break;
+        vb = vb_next;
+        m0 = m0n;
+        n0 = n0n;
+        zero_acc();
+        }
+    }
 }
 
 template <int EPI, bool RESID, int PIPE>
 int launch_one(const GemmArgs& a, hipStream_t s) {
     auto kfn = gemm_nt256_kernel<EPI, RESID, PIPE>;
     DH_MAX_LDS_ONCE(kfn, 4 * TILE_B);
-    hipLaunchKernelGGL(kfn, dim3(a.nb_n * a.nb_m), dim3(512), 4 * TILE_B, s, a);
+    int blocks = a.nb_n * a.nb_m;
+    if (PIPE == 3) {                     // persistent: one block per CU walks the tiles
+        static std::atomic<int> n_cu{0};
+        int cu = n_cu.load(std::memory_order_relaxed);
+        if (cu == 0) {
+            int dev = 0;
+            DH_HIP(hipGetDevice(&dev));
+            DH_HIP(hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev));
+            n_cu.store(cu, std::memory_order_relaxed);
+        }
+        blocks = blocks < cu ? blocks : cu;
+    }
+    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(512), 4 * TILE_B, s, a);
     DH_LAUNCH_CHECK();
     return 0;
 }
@@ -502,6 +543,9 @@ int launch_one(const GemmArgs& a, hipStream_t s) {
 template <int EPI>
 int launch(const GemmArgs& a, hipStream_t s) {
     // 1: ping-pong (default), 2: 4-stage pipeline with both waves of a SIMD in phase, 3: BK = 64 double buffer
+    // 4: persistent ping-pong where its loop-carried state fits the registers (the LoRA epilogues spill 47-116 VGPRs)
+    if (g_gemm_variant == 4 && (EPI == DH_EPI_PLAIN || EPI == DH_EPI_SWIGLU))
+        return a.resid ? launch_one<EPI, true, 3>(a, s) : launch_one<EPI, false, 3>(a, s);
     if (g_gemm_variant == 3) return a.resid ? launch_one<EPI, true, 0>(a, s) : launch_one<EPI, false, 0>(a, s);
     if (g_gemm_variant == 2) return a.resid ? launch_one<EPI, true, 1>(a, s) : launch_one<EPI, false, 1>(a, s);
     return a.resid ? launch_one<EPI, true, 2>(a, s) : launch_one<EPI, false, 2>(a, s);

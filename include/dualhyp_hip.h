@@ -31,7 +31,7 @@ typedef uint16_t dh_bf16;
 int dh_abi_version(void);
 /* Kernel-variant selector for A/B measurements inside one process (bench.py --tune k=v); never needed in production,
  * keys 4, 10 and 16 select a different fp32 summation order (low bits change), no other key changes a result bit.  Keys: 0 decode partial-sum GEMM (0 = K split over the waves of a block,
- * 1 = row-parallel with x staged in LDS); 1 prefill GEMM (0 = always 128x128 tiles, 1..3 = 256x256 loop variants);
+ * 1 = row-parallel with x staged in LDS); 1 prefill GEMM (0 = always 128x128 tiles, 1..3 = 256x256 loop variants, 4 = persistent blocks, the default);
  * 2 SwiGLU streaming variant; 3 gemm_mid on/off; 4 phase pin of dh_linear_bf16 (0 by shape, 1 tiled, 2 decode);
  * 5 band height of the 256-tile walk; 6 / 7 first row count of the tiled decode kernels (fused epilogues / chain sums);
  * 8 gemm_dt stages; 9 128-tile stages; 10 decode steps from this many rows on the prefill kernels (0 = never);
