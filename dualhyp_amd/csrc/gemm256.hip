@@ -92,32 +92,45 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
             lbv[i] = kg < 2 ? *reinterpret_cast<const bf16x8*>(a.lora_b + (size_t)nn * 16 + kg * 8) : zero8;   // rank 16 zero-padded to K = 32
         }
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    // The per-strip operands (x·A^T fragment per tile pair, residual words) of strip j+1 are requested BEFORE strip j is
+    // finished and stored: y may alias resid, so the compiler keeps every load behind the previous strip's stores, and a
+    // strip then starts with an exposed L2 round trip (four per tile, tools/probe_gemm256.py).  Different strips touch
+    // different rows, so the reordering is safe when y == resid.  LoRA segments start at multiples of 32 columns: one
+    // fragment per PAIR of column tiles.
+    bf16x8 xfv2[2][LORA ? NT / 2 : 1];
+    uint4 rrv2[2][RESID ? NT / 2 : 1];
+    auto load_strip = [&](int j, bf16x8 (&xf)[LORA ? NT / 2 : 1], uint4 (&rr)[RESID ? NT / 2 : 1]) __attribute__((always_inline)) {
         const int m = m0 + wm * 64 + j * 16 + frow;
         const bool m_ok = m < a.M;
-        bf16x8 xfv[LORA ? NT : 1];
         if (LORA && a.lora_b != nullptr) {
             const int mm = m_ok ? m : a.M - 1;
 #pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const int nt = nw0 + i * 16;
+            for (int i = 0; i < NT / 2; ++i) {
+                const int nt = nw0 + i * 32;
                 const int seg = (nt >= a.split0) + (nt >= a.split1);
-                xfv[i] = kg < 2 ? *reinterpret_cast<const bf16x8*>(a.xa + (size_t)mm * a.xa_ld + seg * 16 + kg * 8) : zero8;
+                xf[i] = kg < 2 ? *reinterpret_cast<const bf16x8*>(a.xa + (size_t)mm * a.xa_ld + seg * 16 + kg * 8) : zero8;
             }
         }
         // residual in the layout of the paired 16-byte stores below (8 consecutive columns per lane): the add is done
         // after the permlane swap, on values that are already bf16-exact, so the rounding is that of bf16(resid + y)
-        uint4 rrv[RESID ? NT / 2 : 1];
         if (RESID) {
 #pragma unroll
             for (int ip = 0; ip < NT / 2; ++ip) {
                 const int nb = nw0 + ip * 32;
-                rrv[ip] = (m_ok && nb + 32 <= a.N)
-                              ? *reinterpret_cast<const uint4*>(a.resid + (size_t)m * a.N + nb + (kg & 1) * 16 + (kg >> 1) * 8)
-                              : make_uint4(0, 0, 0, 0);
+                rr[ip] = (m_ok && nb + 32 <= a.N)
+                             ? *reinterpret_cast<const uint4*>(a.resid + (size_t)m * a.N + nb + (kg & 1) * 16 + (kg >> 1) * 8)
+                             : make_uint4(0, 0, 0, 0);
             }
         }
+    };
+    load_strip(0, xfv2[0], rrv2[0]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wm * 64 + j * 16 + frow;
+        const bool m_ok = m < a.M;
+        if (j + 1 < 4) load_strip(j + 1, xfv2[(j + 1) & 1], rrv2[(j + 1) & 1]);
+        bf16x8 (&xfv)[LORA ? NT / 2 : 1] = xfv2[j & 1];
+        uint4 (&rrv)[RESID ? NT / 2 : 1] = rrv2[j & 1];
         if constexpr (EPI == DH_EPI_QKV) {
             // ---- fused-QKV epilogue: finish LoRA, then per head of the wave's 128 columns rotate (q, k) and scatter
             // q -> q_out [tok, head, hs], k -> K cache, v -> V^T cache (fragment order, common.h), exactly the arithmetic
@@ -129,7 +142,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
                 for (int e = 0; e < 4; ++e) ov[i][e] = rbf(acc[i][j][e]);
                 if (a.lora_b != nullptr) {
                     f32x4 lacc = {0.f, 0.f, 0.f, 0.f};
-                    lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lbv[i], xfv[i], lacc, 0, 0, 0);
+                    lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lbv[i], xfv[i >> 1], lacc, 0, 0, 0);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ov[i][e] = rbf(ov[i][e] + rbf(rbf(lacc[e]) * a.lora_scale));
                 }
@@ -223,7 +236,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
                 for (int e = 0; e < 4; ++e) o[e] = rbf(acc[i][j][e]);
                 if (EPI == DH_EPI_LORA) {
                     f32x4 lacc = {0.f, 0.f, 0.f, 0.f};
-                    lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lbv[LORA ? i : 0], xfv[LORA ? i : 0], lacc, 0, 0, 0);
+                    lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lbv[LORA ? i : 0], xfv[LORA ? i >> 1 : 0], lacc, 0, 0, 0);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = rbf(o[e] + rbf(rbf(lacc[e]) * a.lora_scale));
                 }

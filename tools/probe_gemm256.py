@@ -19,8 +19,19 @@ def stamps(n):
     buf = np.zeros(8192 * 4, dtype=np.uint64)
     assert raw.dh_debug_g256_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
     return buf.reshape(8192, 4)[:n].astype(np.int64)
+lib.dh_set_tuning(1, 1)      # per-tile launches: a block = a tile
+H, G, hs, S = 32, 4, 64, 512
+Wq, Wp = rn(2560, d), rn(d, d)
+xa48, xa16, Bq, Bp = rn(M, 48), rn(M, 16), rn(2560, 16), rn(d, 16)
+cos, sin = rn(S, hs), rn(S, hs)
+nseq = M // S
+kc = torch.zeros(nseq, G, S, hs, device=D, dtype=torch.bfloat16); vt = torch.zeros(nseq, G, hs, S, device=D, dtype=torch.bfloat16)
+tok_slot = torch.arange(nseq, device=D, dtype=torch.int32).repeat_interleave(S)
+tok_pos = torch.arange(S, device=D, dtype=torch.int32).repeat(nseq)
 for (nm, fn, nblk) in (("SwiGLU (K 2048)", lambda: ops.linear(x, W1, epilogue=ops.EPI_SWIGLU, w2=W2), 128 * 44),
-                       ("mlp proj + residual (K 5632)", lambda: ops.linear(act, Wm, resid=x), 128 * 8)):
+                       ("mlp proj + residual (K 5632)", lambda: ops.linear(act, Wm, resid=x), 128 * 8),
+                       ("QKV + LoRA + rope + cache append", lambda: ops.linear_qkv_rope_cache(x, Wq, cos, sin, tok_slot, tok_pos, kc, vt, H, G, xa=xa48, lora_b=Bq), 128 * 10),
+                       ("attn proj + LoRA + residual", lambda: ops.linear(x, Wp, epilogue=ops.EPI_LORA, xa=xa16, lora_b=Bp, lora_scale=1.0, splits=(d, d), resid=x), 128 * 8)):
     for _ in range(2): fn()
     torch.cuda.synchronize()
     st = stamps(nblk)
