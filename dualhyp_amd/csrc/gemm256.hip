@@ -123,6 +123,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
             }
         }
     };
+    // fused-QKV epilogue: the token positions / cache slots of all four row strips up front (the rope tables are
+    // indexed by them: one dependent round trip per strip less)
+    int posv[EPI == DH_EPI_QKV ? 4 : 1], slotv[EPI == DH_EPI_QKV ? 4 : 1];
+    if constexpr (EPI == DH_EPI_QKV) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int mm = m0 + wm * 64 + j * 16 + frow;
+            mm = mm < a.M ? mm : a.M - 1;
+            posv[j] = a.tok_pos[mm];
+            slotv[j] = a.tok_slot[mm];
+        }
+    }
     load_strip(0, xfv2[0], rrv2[0]);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -151,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
                 // every lane runs the arithmetic and the lane swaps (rows past M use the last row's position); only the
                 // stores are predicated
                 const int mm = m_ok ? m : a.M - 1;
-                const int pos = a.tok_pos[mm], slot = a.tok_slot[mm];
+                const int pos = posv[EPI == DH_EPI_QKV ? j : 0], slot = slotv[EPI == DH_EPI_QKV ? j : 0];
                 const int qpk = a.n_head / a.n_groups;
                 // two adjacent 16-column tiles -> 8 consecutive columns per lane (as the paired stores of the other epilogues)
                 auto pair16 = [&](uint2 ta, uint2 tb) __attribute__((always_inline)) -> uint4 {
