@@ -288,7 +288,7 @@ int dh_linear_impl(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N,
     DH_CHECK(N % 8 == 0, "dh_linear_bf16: N=%d must be a multiple of 8", N);
     DH_CHECK(x && w && y, "dh_linear_bf16: null operand");
     if (M == 0) return 0;
-    GemmArgs a;
+    GemmArgs a{};
     a.x = x; a.w = w; a.w2 = w2; a.y = y; a.xa = xa; a.lora_b = lora_b; a.vec_a = vec_a; a.vec_b = vec_b;
     a.resid = resid; a.M = M; a.N = N; a.K = K; a.xa_ld = xa_ld; a.split0 = split0; a.split1 = split1;
     a.lora_scale = lora_scale;
