@@ -276,7 +276,7 @@ def main() -> None:
         flops = gemm_flops_per_prefill(cfg, sum(p.numel() for p in timed_prompts), B * a.steps, merged_lora=wl["fp8"])
         achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         traffic = None   # HBM-side bytes per launch from the committed PMC passes
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_gemm.json")
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_gemm_v2.json")
         if os.path.exists(pmc) and a.config == "tinyllama-bf16":
             with open(pmc) as fh:
                 traffic = json.load(fh).get("traffic_bytes_per_launch_mean")
@@ -295,7 +295,7 @@ def main() -> None:
             "roofline": {"bound": "mfma", "kernel": wl["kernel"],
                          "achieved": achieved, "peak": wl["peak"], "unit": "TFLOP/s",
                          "frac": achieved / wl["peak"], "traffic": traffic,
-                         "traffic_source": "profiles/r02_pmc_gemm.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_gemm.py, mean bytes per launch; L2-miss traffic on the fabric, Infinity-Cache hits included)",
+                         "traffic_source": "profiles/r02_pmc_gemm_v2.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_gemm.py, mean bytes per launch; L2-miss traffic on the fabric, Infinity-Cache hits included)",
                          "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
                          "prefill_attention_ms_per_step": attn_ms / max(a.steps, 1)},
         }
