@@ -2,7 +2,7 @@
 """Race screen for the kernels whose LDS hand-over rests on counted s_waitcnt + raw s_barrier (cdna_hip_programming.md
 §5 'place reads by the vmcnt/barrier count, never by clean runs'): many launches on fresh random data, several
 shapes, compared bit for bit with a structurally different kernel that computes the same chains.
-  * 256-tile GEMM: ping-pong loop (variant 1) and 4-stage loop (2) vs the __syncthreads double buffer (3)
+  * 256-tile GEMM: ping-pong loop (variant 1), 4-stage loop (2) and persistent ping-pong blocks (4) vs the __syncthreads double buffer (3)
   * 128-tile GEMM: 4-stage counted-wait loop vs the 2-stage __syncthreads loop
   * decode GEMMs: gemm_mid (loader waves) vs gemm_dt (tiled) rows; tiled chain vs ordered sum of K-sliced partials"""
 import sys, torch
@@ -23,20 +23,22 @@ for (M, N, K) in [(16384, 2560, 2048), (4096, 2048, 5632), (1024, 768, 512), (77
     for it in range(REPS):
         x, w, r = rn(M, K), rn(N, K) * 0.1, rn(M, N)
         outs = []
-        for v in (3, 1, 2):
+        for v in (3, 1, 2, 4):
             lib.dh_set_tuning(1, v)
             outs.append(ops.linear(x, w, resid=r))
         check(f"gemm256 pingpong M={M} N={N} K={K} it={it}", outs[1], outs[0])
         check(f"gemm256 pipe M={M} N={N} K={K} it={it}", outs[2], outs[0])
+        check(f"gemm256 persistent M={M} N={N} K={K} it={it}", outs[3], outs[0])
         if N % 64 == 0 and it % 4 == 0:
             w2 = rn(N, K) * 0.1
             so = []
-            for v in (3, 1):
+            for v in (3, 1, 4):
                 lib.dh_set_tuning(1, v)
                 so.append(ops.linear(x, w, epilogue=ops.EPI_SWIGLU, w2=w2))
             check(f"gemm256 swiglu M={M} N={N} K={K} it={it}", so[1], so[0])
+            check(f"gemm256 swiglu persistent M={M} N={N} K={K} it={it}", so[2], so[0])
     print(f"gemm256 {M}x{N}x{K}: {REPS} runs done", flush=True)
-lib.dh_set_tuning(1, 1)
+lib.dh_set_tuning(1, 4)
 for (M, N, K) in [(560, 2048, 2048), (560, 2560, 2048), (200, 512, 5632), (100, 128, 64)]:
     for it in range(REPS):
         x, w = rn(M, K), rn(N, K) * 0.1
@@ -45,15 +47,22 @@ for (M, N, K) in [(560, 2048, 2048), (560, 2560, 2048), (200, 512, 5632), (100, 
         lib.dh_set_tuning(9, 4); b = ops.linear(x, w)
         check(f"gemm128 4-stage M={M} N={N} K={K} it={it}", b, a)
     print(f"gemm128 {M}x{N}x{K}: {REPS} runs done", flush=True)
-lib.dh_set_tuning(1, 1); lib.dh_set_tuning(9, 0)
+lib.dh_set_tuning(1, 4); lib.dh_set_tuning(9, 0)
 lib.dh_set_tuning(4, 2)
 for (M, d, I) in [(256, 2048, 5632), (1024, 2048, 5632), (100, 512, 768)]:
     for it in range(REPS):
         x, w1, w2 = rn(M, d), rn(I, d) * 0.1, rn(I, d) * 0.1
         lib.dh_set_tuning(6, 1 << 20); a = ops.linear(x, w1, epilogue=ops.EPI_SWIGLU, w2=w2)     # gemm_mid
         for st in (2, 4):
-            lib.dh_set_tuning(6, 65); lib.dh_set_tuning(8, st); b = ops.linear(x, w1, epilogue=ops.EPI_SWIGLU, w2=w2)   # gemm_dt
-            check(f"mid vs dt({st}) swiglu M={M} d={d} it={it}", b, a)
+            for wide in (-1, 1):
+                lib.dh_set_tuning(6, 65); lib.dh_set_tuning(8, st); lib.dh_set_tuning(15, wide)
+                b = ops.linear(x, w1, epilogue=ops.EPI_SWIGLU, w2=w2)   # gemm_dt, 4-wave / 8-wave SwiGLU tile
+                check(f"mid vs dt({st}, wide {wide}) swiglu M={M} d={d} it={it}", b, a)
+        lib.dh_set_tuning(15, 0)
+        # <= 64 rows: W through the per-wave LDS ring (LDS-DMA, counted vmcnt) vs W straight to VGPRs
+        xs = x[:48].contiguous()
+        lib.dh_set_tuning(6, 1 << 20); lib.dh_set_tuning(13, 0); a48 = ops.linear(xs, w1, epilogue=ops.EPI_SWIGLU, w2=w2)
+        lib.dh_set_tuning(13, 1); check(f"mid LDS ring vs VGPR M=48 d={d} it={it}", ops.linear(xs, w1, epilogue=ops.EPI_SWIGLU, w2=w2), a48)
         A = rn(48, d) * 0.1
         wq = rn(d + 512, d) * 0.1
         ks = (d // 32 + 7) // 8
@@ -65,6 +74,12 @@ for (M, d, I) in [(256, 2048, 5632), (1024, 2048, 5632), (100, 512, 768)]:
         for st in (2, 4):
             lib.dh_set_tuning(8, st)
             check(f"chain({st}) vs partials M={M} d={d} it={it}", ops.linear_chain(x, wq, A, ksplit=ks), seq)
+        # the K-sliced kernel (LDS-DMA double-buffered x rounds, full-line stores): 8 vs 10 row groups per block, and
+        # rows of a wide call vs the same rows alone (different round structure)
+        lib.dh_set_tuning(14, 8); p8 = ops.linear_partial(x, wq, A, ksplit=ks)
+        lib.dh_set_tuning(14, 10); check(f"partials 10 vs 8 groups M={M} d={d} it={it}", ops.linear_partial(x, wq, A, ksplit=ks), p8)
+        lib.dh_set_tuning(14, 0)
+        check(f"partials rows alone M={M} d={d} it={it}", ops.linear_partial(x[32:64].contiguous(), wq, A, ksplit=ks), parts[:, 32:64])
     print(f"decode GEMMs M={M} d={d}: {REPS} runs done", flush=True)
 lib.dh_set_tuning(6, 193); lib.dh_set_tuning(7, 768); lib.dh_set_tuning(8, 0); lib.dh_set_tuning(4, 0)
 print("race screen:", "CLEAN" if bad == 0 else f"{bad} MISMATCHES")
