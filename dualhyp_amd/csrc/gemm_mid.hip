@@ -5,7 +5,9 @@
 //   block : 640 threads = 8 compute waves (RS row sets x KQ K-parts) + 2 loader waves; a compute wave owns 16 W rows (SWIGLU: of fc_1
 //           AND fc_2) and one contiguous K-part; a slice holds KSL/KQ k-steps of EVERY part, so a block covers only 16*RS output
 //           columns and even N = 5632 puts 176 blocks on the chip (SWIGLU: RS 2 x KQ 4, else 4 x 2)
-//   W     : global -> VGPR, ring of 8 slices per wave: 14 KiB in flight per wave, 112 KiB per block
+//   W     : up to 64 rows (WL): global -> a PRIVATE per-wave LDS ring by LDS-DMA in full 128-B lines (12-16 KiB per wave,
+//           ordered by the wave's own counted vmcnt, no barrier), fragments read back with ds_read_b128;
+//           above: global -> VGPR in fragment shape, ring of 8 slices per wave (14 KiB in flight per wave)
 //   x     : rows [m0, m0 + 32*NG) x 128 k per slice, global -> LDS directly (global_load_lds, 16 B per
 //           lane) by the two loader waves, 4 buffers, requested 3 slices ahead; 256-B rows, 16-B chunk
 //           index XOR (row & 15) applied on the SOURCE address so the fragment reads are conflict free

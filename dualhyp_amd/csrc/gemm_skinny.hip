@@ -262,15 +262,16 @@ __global__ __launch_bounds__(512, 2) void gemm_skinny_partial_kernel(const bf16_
 }
 
 // Row-parallel variant: the 8 waves of a block own 16*CT W rows EACH (128*CT rows per block) and all
-// work on the SAME K-slice, so the x slice [32*NG x 32*KPS] is staged once per block in LDS (x is
-// 2/3 of the load instructions when every wave fetches its own fragments) and no cross-wave
-// reduction is needed: each wave stores its fp32 tiles straight from the accumulators.  NG 32-row
-// groups of x (several batches decoded in one launch) reuse the W fragments held in registers; when
-// NG groups do not fit in LDS they pass through it NGL at a time (W is still streamed once).
+// work on the SAME K-slice, so no cross-wave reduction is needed: each wave stores its fp32 tiles straight from
+// the accumulators (as full 128-B lines when it owns two adjacent column tiles).  W is fetched once per block as
+// full 128-B lines and held as MFMA fragments in registers; NG 32-row groups of x (several batches decoded in one
+// launch) pass through LDS in double-buffered rounds of NGL groups (LDS-DMA) and reuse those fragments.
 // CT (column tiles per wave): with one tile every MFMA needs its own ds_read_b128 of x and from ~128 rows on the
 // LDS port, not the weight stream, bounds the kernel (rocprof at 640 rows: 275-316 TFLOP/s); with CT tiles one x
 // fragment feeds CT MFMAs.  The summation order is untouched: same K-slices, same chain inside a slice.
 //   grid (ceil(N/(128*CT)), ksplit, ceil(M / (32*NG))), K-slice = KPS k-steps of 32.
+// PSTORE: the partial-sum store; -DDH_ROWS_NT_STORE (non-temporal) was measured and is slower end to end (the consumers
+// then read the partials from HBM instead of the caches).
 #ifdef DH_ROWS_NT_STORE
 #define PSTORE(p, v) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p))
 #else
