@@ -232,8 +232,8 @@ int launch_dt_n(const DtArgs& a, int blocks, hipStream_t s) {
 template <int MODE>
 int launch_dt(const DtArgs& a, hipStream_t s) {
     const int m_tiles = cdiv(a.M, TB);
-    if (MODE == 1 && (g_dt_wide ? g_dt_wide > 0 : a.M >= 256))
-        return launch_dt_n<1, 3, 4>(a, m_tiles * cdiv(a.N, 128), s);
+    if ((MODE == 1 || MODE == 2) && (g_dt_wide ? g_dt_wide > 0 : a.M >= 256))
+        return launch_dt_n<MODE == 2 ? 2 : 1, 3, 4>(a, m_tiles * cdiv(a.N, MODE == 1 ? 128 : 256), s);
     const int n_tiles = cdiv(a.N, MODE == 1 ? 64 : TB);
     const int blocks = m_tiles * n_tiles;
     // more than one block per CU to go round: two co-resident blocks hide each other's waits better than

@@ -21,4 +21,15 @@ for M in (200, 256, 384, 512, 640, 1024, 2048):
         t = bench(lambda i: ops.linear(x, W1[i % L], epilogue=ops.EPI_SWIGLU, w2=W2[i % L]))
         print(f"M={M:5d} wide={wide:2d}: {t:6.1f} us  {2*M*d*2*I/t/1e6:6.0f} TFLOP/s", flush=True)
     print("        same bits:", bool(torch.equal(out[-1], out[1])))
+Wl = [torch.randn(32000, d, device=D).bfloat16() * 0.02 for _ in range(3)]
+sc = (1 + 0.1 * torch.randn(32000, device=D)).bfloat16(); bi = (0.1 * torch.randn(32000, device=D)).bfloat16()
+for M in (256, 640, 2048):
+    x = torch.randn(M, d, device=D).bfloat16()
+    out = {}
+    for wide in (-1, 1):
+        lib.dh_set_tuning(15, wide)
+        out[wide] = ops.linear(x, Wl[0], epilogue=ops.EPI_ADAPTER, scale=sc, bias=bi)
+        t = bench(lambda i: ops.linear(x, Wl[i % 3], epilogue=ops.EPI_ADAPTER, scale=sc, bias=bi))
+        print(f"lm_head M={M:5d} wide={wide:2d}: {t:6.1f} us  {2*M*d*32000/t/1e6:6.0f} TFLOP/s", flush=True)
+    print("        same bits:", bool(torch.equal(out[-1], out[1])))
 lib.dh_set_tuning(15, 0)
