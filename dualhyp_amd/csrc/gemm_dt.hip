@@ -251,9 +251,10 @@ int launch_dt(const DtArgs& a, hipStream_t s) {
 //   mlp'     K-sliced rows kernel | this kernel (chain mode)    27|81  50|81  76|82 150|83
 // A block walks K sequentially (about 1 us per 64-wide stage however many stages are in flight), so the
 // chain mode costs a constant ~nk us until the m-tiles fill the chip, while K-slicing across blocks scales
-// with the rows: the crossover is near 768 rows.
+// with the rows: the crossover was near 768 rows in round 1; with round 2's K-sliced kernel it lies between 1024 and 2048.
 int g_dt_min_rows = 193;       // fused-epilogue decode GEMMs from this many rows on (dh_set_tuning key 6)
-int g_chain_min_rows = 768;    // partial-sum GEMMs from this many rows on (dh_set_tuning key 7)
+int g_chain_min_rows = 1280;   // partial-sum GEMMs from this many rows on (dh_set_tuning key 7): the K-sliced kernel wins at 1024 rows
+                               // (8.34 vs 8.53 ms per decode step), this kernel at 2048 (12.9 vs 14.6)
 
 // x·[w; w_ext]^T summed over the K-slices of `kps` k-steps in slice order: fp32 [M][n_main + n_ext]
 int dh_chain_tiled(const bf16_t* x, const bf16_t* w, const bf16_t* w_ext, float* y32, int M, int n_main, int n_ext, int K,

@@ -119,7 +119,7 @@ int dh_linear_qkv_rope_cache_bf16(const dh_bf16* x, const dh_bf16* w, int M, int
 int dh_linear_partial_bf16(const dh_bf16* x, const dh_bf16* w, const dh_bf16* w_ext, float* y32,
                            int M, int n_main, int n_ext, int K, int ksplit, void* stream);
 /* The ksplit partial sums of dh_linear_partial_bf16 added in slice order, in one launch (tiled kernel, for at least
- * dh_set_tuning(7, min_rows) rows — default 768, below that the K-sliced kernel is faster): y32 [M][n_main+n_ext] fp32, bit-identical to adding the partials
+ * dh_set_tuning(7, min_rows) rows — default 1280, below that the K-sliced kernel is faster): y32 [M][n_main+n_ext] fp32, bit-identical to adding the partials
  * p = 0..ksplit-1 sequentially in fp32.  Consumers take it with n_part = 1.  Needs K %% 64 == 0 and
  * K-slices of 8 or 16 k-steps (ceil(K/32/ksplit)); other shapes return an error. */
 int dh_linear_chain_bf16(const dh_bf16* x, const dh_bf16* w, const dh_bf16* w_ext, float* y32, int M,

@@ -222,11 +222,11 @@ def test_joint_decode_is_batch_invariant(golden, name):
     g = torch.Generator().manual_seed(7)
     prompts = [torch.randint(3, V, (int(n),), generator=g).to(DEV) for n in torch.randint(5, 40, (70,), generator=g)]
     G = 9
-    # beyond 192 rows the SwiGLU / lm_head GEMMs switch to the tiled kernel (gemm_dt.hip), beyond 768 the
+    # beyond 192 rows the SwiGLU / lm_head GEMMs switch to the tiled kernel (gemm_dt.hip), from 1280 rows the
     # partial-sum GEMMs too (its chain mode, consumers then see one partial) — same bits either way
     joint = [o.cpu() for o in generate_batch(m, prompts, G, temperature=0.2, top_k=1, prefill_batch=16)]
     assert len(joint) == 70
-    for reps in (3, 12):
+    for reps in (3, 12, 20):                                   # 210, 840 and 1400 rows
         big = [o.cpu() for o in generate_batch(m, prompts * reps, G, temperature=0.2, top_k=1, prefill_batch=64)]
         assert len(big) == 70 * reps
         assert all(torch.equal(big[i], joint[i % 70]) for i in range(70 * reps)), f"{70 * reps}-row decode differs from the 70-row decode"

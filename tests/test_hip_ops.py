@@ -248,7 +248,7 @@ def test_linear_partial_wide_rows(dev, M, N, n_ext, K, ks):
         try:
             chain = ops.linear_chain(x, W, A, ksplit=ks)
         finally:
-            _lib.load().dh_set_tuning(7, 768)
+            _lib.load().dh_set_tuning(7, 1280)
         assert torch.equal(chain, seq), "tiled chain sum differs from the ordered sum of the streamed partials"
     else:
         with pytest.raises(Exception):
