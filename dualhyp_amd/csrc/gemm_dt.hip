@@ -252,7 +252,8 @@ int launch_dt(const DtArgs& a, hipStream_t s) {
 // A block walks K sequentially (about 1 us per 64-wide stage however many stages are in flight), so the
 // chain mode costs a constant ~nk us until the m-tiles fill the chip, while K-slicing across blocks scales
 // with the rows: the crossover was near 768 rows in round 1; with round 2's K-sliced kernel it lies between 1024 and 2048.
-int g_dt_min_rows = 193;       // fused-epilogue decode GEMMs from this many rows on (dh_set_tuning key 6)
+int g_dt_min_rows = 129;       // fused-epilogue decode GEMMs from this many rows on (dh_set_tuning key 6); the lm_head (N = 32000) already
+                               // from 65: measured SwiGLU 24 (streaming) vs 32 us at 128 rows, 40 vs 32 at 130; lm_head 49 vs 39 at 96 rows
 int g_chain_min_rows = 1280;   // partial-sum GEMMs from this many rows on (dh_set_tuning key 7): the K-sliced kernel wins at 1024 rows
                                // (8.34 vs 8.53 ms per decode step), this kernel at 2048 (12.9 vs 14.6)
 
@@ -264,7 +265,7 @@ int dh_chain_tiled(const bf16_t* x, const bf16_t* w, const bf16_t* w_ext, float*
 }
 
 bool dh_linear_dt_ok(const GemmArgs& a, int epilogue, int seg) {
-    return a.M >= g_dt_min_rows && a.K % BKD == 0 && seg > 0 && seg % 2 == 0 && (a.K / 32) % seg == 0 && a.N % 4 == 0 &&
+    return a.M >= (epilogue == DH_EPI_ADAPTER ? (g_dt_min_rows < 65 ? g_dt_min_rows : 65) : g_dt_min_rows) && a.M > 64 && a.K % BKD == 0 && seg > 0 && seg % 2 == 0 && (a.K / 32) % seg == 0 && a.N % 4 == 0 &&
            (epilogue == DH_EPI_PLAIN || epilogue == DH_EPI_SWIGLU || epilogue == DH_EPI_ADAPTER);
 }
 

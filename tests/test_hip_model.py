@@ -222,7 +222,7 @@ def test_joint_decode_is_batch_invariant(golden, name):
     g = torch.Generator().manual_seed(7)
     prompts = [torch.randint(3, V, (int(n),), generator=g).to(DEV) for n in torch.randint(5, 40, (70,), generator=g)]
     G = 9
-    # beyond 192 rows the SwiGLU / lm_head GEMMs switch to the tiled kernel (gemm_dt.hip), from 1280 rows the
+    # beyond 128 rows the SwiGLU (64: lm_head) GEMMs switch to the tiled kernel (gemm_dt.hip), from 1280 rows the
     # partial-sum GEMMs too (its chain mode, consumers then see one partial) — same bits either way
     joint = [o.cpu() for o in generate_batch(m, prompts, G, temperature=0.2, top_k=1, prefill_batch=16)]
     assert len(joint) == 70

@@ -274,7 +274,7 @@ def test_decode_phase_linear_rows_invariant(dev, d, I, V):
         "plain+resid": lambda xs, sl: ops.linear(act[sl].contiguous(), wp, resid=res[sl].contiguous()),
     }
     lib.dh_set_tuning(4, 2)          # public dh_linear_bf16 in the decode phase
-    lib.dh_set_tuning(6, 65)         # tiled kernel from 65 rows on (default 193)
+    lib.dh_set_tuning(6, 65)         # tiled kernel from 65 rows on (default 129; lm_head 65)
     try:
         for name, fn in calls.items():
             whole = fn(x, slice(0, M))
@@ -286,7 +286,7 @@ def test_decode_phase_linear_rows_invariant(dev, d, I, V):
             assert torch.equal(fn(x[sl].contiguous(), sl), whole[sl]), name
     finally:
         lib.dh_set_tuning(4, 0)
-        lib.dh_set_tuning(6, 193)
+        lib.dh_set_tuning(6, 129)
 
 
 def _attn_setup(dev, hs, n_head, n_groups, lens, pos0, s_max, seed):
