@@ -15,7 +15,7 @@ Data-parallel replicas: every rank decodes its own batch, no collective in the d
 (SURVEY.md §8e); value = utterances of all ranks / max-over-ranks time.  Rank 0 prints ONE JSON
 line with the `roofline` of the dominant kernel class (prefill MFMA GEMMs, timed live with HIP
 events on the launch stream) and, at N=1, the `cpu_baseline` (the oracle = CPU restatement of
-the reference, timed on this host's cores on one utterance of the same workload).
+the reference, timed on this host's cores on 8 utterances of the same workload after one warm-up).
 """
 from __future__ import annotations
 
@@ -347,10 +347,10 @@ def main() -> None:
         # "bounded sample" contract of the default run; parity of this path is asserted in tests/test_hip_fp8.py
         result["cpu_baseline"] = None
     elif rank == 0 and world == 1 and not a.no_cpu_baseline:
-        # the oracle decodes the FIRST TIMED utterance; its ids and logits are the checker for what the timed run
-        # produced for that prompt (parity), its wall time is the CPU baseline
-        result["cpu_baseline"], ref = cpu_baseline(cfg, timed_prompts[0].cpu(), NEW_TOKENS)
-        result["parity"] = parity_vs_oracle(model, timed_prompts[0], outs[0][0], ref, gen_kw)
+        # the oracle decodes the first utterances of the timed region; its ids and logits are the checker for what the
+        # timed run produced for those prompts (parity), its wall time is the CPU baseline
+        result["cpu_baseline"], refs = cpu_baseline(cfg, timed_prompts[:9], NEW_TOKENS)
+        result["parity"] = parity_vs_oracle(model, timed_prompts, [o for out in outs for o in out], refs, gen_kw)
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
@@ -394,7 +394,7 @@ def bench_finetune(a, wl, cfg, model, dev, rank: int, world: int, rehearsal: boo
         loss = None
         for i in range(per_rank):
             j = (k * per_rank + i) % len(mine)
-            loss = step_fn(mine[j], labs[j], 1.0 / GLOBAL)
+            loss = step_fn(mine[j], labs[j], 1.0 / per_rank)   # mean over this rank's micro-batches; all_reduce_mean then averages the ranks (as fit() does)
         bucket.all_reduce_mean()
         opt.step()
         bucket.zero()
@@ -435,70 +435,131 @@ def bench_finetune(a, wl, cfg, model, dev, rank: int, world: int, rehearsal: boo
         dist.destroy_process_group()
 
 
-def cpu_baseline(cfg, prompt, new_tokens: int):
-    """The oracle (CPU restatement of ger/lora.py + generate/base.py, pinned to the reference by
-    tests/golden) timed on this host: ONE utterance of the same workload, batch 1 as the
-    reference runs it (inference/ger.py:60-81).  -> (baseline dict, (ids, per-step logits) of the first run)."""
+def _cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
+N_PARITY = 4      # utterances of the timed region the oracle's ids / prefill logits are compared on
+
+
+def cpu_baseline(cfg, prompts, new_tokens: int):
+    """The oracle (CPU restatement of ger/lora.py + generate/base.py, pinned to the reference by tests/golden) timed on
+    this host in BASELINE.md §4's form: batch 1 as the reference runs it (inference/ger.py:60-81), ONE warm-up
+    utterance, then 8 utterances of the same workload one after the other (~25 s of CPU work); utterances/s, prefill
+    seconds and ms per generated token, thread and core counts, CPU model.  The ids and per-step logits the oracle
+    produced for the first N_PARITY timed utterances are returned as the checker for the GPU run (`parity`), together
+    with the oracle's fp32 last-position prefill logits for them (the yardstick of the logit gate)."""
     from dualhyp_amd.synth import synth_state_dict
     from oracle import ger_oracle as O
     torch.set_num_threads(min(os.cpu_count() or 1, 16))   # the box's CPU share for one GPU
     sd = synth_state_dict(cfg, seed=1337, device="cpu", **SYNTH_KW)
     m = O.OracleGPT(cfg, sd)
-    T = prompt.numel()
-    n, t0, first = 0, time.perf_counter(), None
-    while n < 8 and time.perf_counter() - t0 < 10.0:      # ~10-15 s of CPU work
-        out = O.generate(m, prompt.cpu(), T + new_tokens, temperature=0.2, top_k=1, eos_id=None, mode="argmax",
-                         return_logits=first is None)
-        if first is None:
-            first = out
-            out = out[0]
-        assert out.numel() == T + new_tokens
+    kw = dict(temperature=0.2, top_k=1, eos_id=None, mode="argmax")
+    n_timed = min(8, len(prompts) - 1)
+    O.generate(m, prompts[-1].cpu(), prompts[-1].numel() + new_tokens, **kw)      # warm-up (an utterance outside the sample)
+    m.reset_cache()
+    tm, refs = {}, []
+    t0 = time.perf_counter()
+    for k in range(n_timed):
+        T = prompts[k].numel()
+        ids, trace = O.generate(m, prompts[k].cpu(), T + new_tokens, return_logits=True, timing=tm, **kw)
+        assert ids.numel() == T + new_tokens
         m.reset_cache()
-        n += 1
-    dt = (time.perf_counter() - t0) / n
-    return {"value": 1.0 / dt, "unit": "utterances/s",
-            "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} utterances one after the other, {T}-token prompt -> {new_tokens} generated tokens, batch 1 "
-                      f"(as the reference runs), bf16, {torch.get_num_threads()} threads ({dt:.1f} s each)"}, first
+        if k < N_PARITY:
+            refs.append([ids, trace])
+    dt = (time.perf_counter() - t0) / n_timed
+    # fp32 run of the same function on the parity utterances' prompts: relRMS(oracle bf16, oracle fp32) is the
+    # distance a bf16 implementation of the reference has from the real-valued function (not part of the timing)
+    m32 = O.OracleGPT(cfg, {k: v.float() for k, v in sd.items()})
+    del sd
+    for k, r in enumerate(refs):
+        T = prompts[k].numel()
+        with torch.inference_mode():
+            r.append(m32(prompts[k].cpu().view(1, -1), torch.arange(T))[0, -1].clone())
+        m32.reset_cache()
+    del m32
+    T0 = prompts[0].numel()
+    base = {"value": 1.0 / dt, "unit": "utterances/s", "cores": torch.get_num_threads(), "kind": "port",
+            "prefill_s": tm["prefill_s"] / n_timed, "decode_ms_per_token": tm["decode_s"] / max(tm["decode_tokens"], 1) * 1e3,
+            "os_cpu_count": os.cpu_count(), "cpu_model": _cpu_model(),
+            "reference_anchor": "the reference itself (ger.lora.GPT + generate.base.generate), 8 vCPU build container: 0.112 utterances/s, "
+                                "prefill 2.97 s, 88.5 ms/token (BASELINE.md §2)",
+            "sample": f"{n_timed} utterances one after the other after 1 warm-up utterance, {T0}-token prompt -> {new_tokens} generated "
+                      f"tokens, batch 1 (as the reference runs), bf16, {torch.get_num_threads()} threads ({dt:.1f} s each)"}
+    return base, refs
 
 
-def parity_vs_oracle(model, prompt, hip_ids_timed, ref, gen_kw) -> dict:
-    """Greedy ids and logits of the HIP path against the oracle's for one utterance of the timed region.  With the
-    tied-head synthetic weights the oracle's top-2 margin is tens of bf16 ulps on every step (reported), so all 64
-    ids must agree; `oracle_tie_free_prefix` counts the leading steps with a margin >= 4 ulps."""
+def parity_vs_oracle(model, prompts, hip_ids_timed, refs, gen_kw) -> dict:
+    """Greedy ids and prefill logits of the HIP path against the oracle's for the first N_PARITY utterances of the timed
+    region.  Ids: with the tied-head synthetic weights the oracle's top-2 margin is tens of bf16 ulps on
+    every step (reported), so all generated ids must agree — this checks the token feedback loop, sampling and cache
+    positions, NOT the attention numerics (the tied ids are a permutation chain of the last token).  The
+    numerics are gated by the logits, which see every layer: relRMS(HIP, oracle bf16) over the last-position prefill
+    logits of the utterances must not exceed relRMS(oracle bf16, oracle fp32) on the same rows."""
     from dualhyp_amd.generate import generate_batch
-    ref_ids, ref_logits = ref
-    T, G = prompt.numel(), ref_logits.size(0)
-    top = torch.topk(ref_logits.float(), 2, dim=-1).values
-    margins = (top[:, 0] - top[:, 1]) / torch.exp2(torch.floor(torch.log2(top[:, 0].abs().clamp_min(1e-30))) - 7)
-    unsafe = (margins < 4).nonzero().flatten().tolist()
-    safe_prefix = unsafe[0] if unsafe else G
+    G = refs[0][1].size(0)
 
-    def prefix(ids) -> int:
+    def margins_of(ref_logits):
+        top = torch.topk(ref_logits.float(), 2, dim=-1).values
+        return (top[:, 0] - top[:, 1]) / torch.exp2(torch.floor(torch.log2(top[:, 0].abs().clamp_min(1e-30))) - 7)
+
+    def prefix(ids, ref_ids, T) -> int:
         ne = (ids.cpu()[T:T + G] != ref_ids[T:T + G]).nonzero().flatten().tolist()
         return ne[0] if ne else G
 
-    out = {"utterance": "first utterance of the timed region", "generated_tokens": G,
-           "oracle_steps_with_margin_ge_4ulp": int((margins >= 4).sum()), "oracle_tie_free_prefix": safe_prefix,
-           "ids_equal_prefix_timed_run": prefix(hip_ids_timed)}
-    # the same prompt alone, and with the CPU-rsqrt emulation the tests use when comparing with CPU tensors (Q11)
+    per, ok_ids = [], True
     keep = model.cpu_rsqrt_vec_width
-    for tag, width in (("alone", keep), ("alone_cpu_rsqrt_emulation", 32)):
-        model.cpu_rsqrt_vec_width = width
-        ids = generate_batch(model, [prompt], G, **gen_kw)[0]
-        out[f"ids_equal_prefix_{tag}"] = prefix(ids)
-        if tag == "alone":
-            out["timed_row_equals_alone_run"] = bool(torch.equal(ids.cpu(), hip_ids_timed.cpu()))
-    with torch.no_grad():
-        model.reset_cache()
-        lg = model(prompt.view(1, -1), torch.arange(T, device=prompt.device))[0, -1].float().cpu()
-        model.reset_cache()
-    model.cpu_rsqrt_vec_width = keep
-    want = ref_logits[0].float()
-    out["prefill_last_logits_rel_rms"] = float(((lg - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt()).item())
-    out["prefill_last_logits_bit_exact_frac"] = float((lg == want).float().mean().item())
-    out["prefill_argmax_equal"] = bool(int(lg.argmax()) == int(want.argmax()))
-    out["pass"] = bool(out["ids_equal_prefix_timed_run"] >= safe_prefix and out["ids_equal_prefix_alone_cpu_rsqrt_emulation"] >= safe_prefix)
+    hip_last, bf_last, f32_last = [], [], []
+    for k, (ref_ids, ref_logits, ref_f32) in enumerate(refs):
+        prompt, T = prompts[k], prompts[k].numel()
+        mg = margins_of(ref_logits)
+        unsafe = (mg < 4).nonzero().flatten().tolist()
+        safe = unsafe[0] if unsafe else G
+        row = {"utterance": k, "oracle_steps_with_margin_ge_4ulp": int((mg >= 4).sum()), "oracle_tie_free_prefix": safe,
+               "min_margin_ulps": float(mg.min()), "ids_equal_prefix_timed_run": prefix(hip_ids_timed[k], ref_ids, T)}
+        # the same prompt alone (product default rounding, then the CPU-rsqrt emulation the tests use against CPU tensors, Q11)
+        for tag, width in (("alone", keep), ("alone_cpu_rsqrt_emulation", 32)):
+            model.cpu_rsqrt_vec_width = width
+            ids = generate_batch(model, [prompt], G, **gen_kw)[0]
+            row[f"ids_equal_prefix_{tag}"] = prefix(ids, ref_ids, T)
+            if tag == "alone":
+                row["timed_row_equals_alone_run"] = bool(torch.equal(ids.cpu(), hip_ids_timed[k].cpu()))
+        with torch.no_grad():
+            model.reset_cache()
+            lg = model(prompt.view(1, -1), torch.arange(T, device=prompt.device))[0, -1].float().cpu()
+            model.reset_cache()
+        model.cpu_rsqrt_vec_width = keep
+        want, f32 = ref_logits[0].float(), ref_f32.float()
+        rel = lambda a, b: float(((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item())
+        row["prefill_last_logits_rel_rms"] = rel(lg, want)
+        row["oracle_bf16_vs_fp32_rel_rms"] = rel(want, f32)
+        row["prefill_last_logits_bit_exact_frac"] = float((lg == want).float().mean().item())
+        row["prefill_argmax_equal"] = bool(int(lg.argmax()) == int(want.argmax()))
+        ok_ids = ok_ids and row["ids_equal_prefix_timed_run"] >= safe and row["ids_equal_prefix_alone_cpu_rsqrt_emulation"] >= safe \
+            and row["timed_row_equals_alone_run"]
+        hip_last.append(lg); bf_last.append(want); f32_last.append(f32)
+        per.append(row)
+    H, Bf, F = torch.stack(hip_last), torch.stack(bf_last), torch.stack(f32_last)
+    rr = float(((H - Bf).pow(2).mean().sqrt() / Bf.pow(2).mean().sqrt()).item())
+    yard = float(((Bf - F).pow(2).mean().sqrt() / F.pow(2).mean().sqrt()).item())
+    e_hip, e_ref = float((H - F).abs().max().item()), float((Bf - F).abs().max().item())
+    out = {"utterances": f"first {len(refs)} utterances of the timed region", "generated_tokens": G,
+           "ids_equal_prefix_timed_run": [r["ids_equal_prefix_timed_run"] for r in per],
+           "oracle_tie_free_prefix": [r["oracle_tie_free_prefix"] for r in per],
+           "ids_note": "tied-head synthetic weights: the ids are a permutation chain of the last token (feedback loop, sampling and "
+                       "cache positions); numerics are gated by the logits below and by tests/ (untied 22-layer fixture)",
+           "prefill_last_logits_rel_rms": rr, "oracle_bf16_vs_fp32_rel_rms": yard,
+           "prefill_last_logits_max_abs_vs_fp32": e_hip, "oracle_bf16_max_abs_vs_fp32": e_ref,
+           "ids_pass": bool(ok_ids), "logits_pass": bool(rr <= yard and e_hip <= 1.5 * e_ref), "per_utterance": per}
+    out["pass"] = bool(out["ids_pass"] and out["logits_pass"])
     return out
 
 

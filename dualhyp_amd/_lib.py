@@ -63,12 +63,15 @@ SIGNATURES = {
     "dh_quant_rows_fp8": (I, [P, P, P, I, I, P]),
     "dh_rmsnorm_quant_fp8": (I, [P, P, P, P, P, I, I, F, P, P]),
     "dh_linear_fp8": (I, [P, P, P, P, P, I, I, I, I, P, P, P, P, P, P]),
+    "dh_linear_fp8_ex": (I, [P, P, P, P, P, I, I, I, I, P, P, P, P, P, I, P]),
     "dh_linear_fp8_f32": (I, [P, P, P, P, P, I, I, I, P]),
     "dh_engine_create": (I, [C.POINTER(ModelDesc), I, I, I, C.POINTER(P)]),
     "dh_engine_destroy": (None, [P]),
     "dh_engine_device_bytes": (I64, [P]),
     "dh_im2col3_bf16": (I, [P, P, I, I, I, I, I, P]),
     "dh_pool_head_bf16": (I, [P, P, P, P, I, I, I, I, P]),
+    "dh_pool_head_bwd_bf16": (I, [P, P, P, P, P, I, I, I, I, P]),
+    "dh_col2im3_bf16": (I, [P, P, P, P, I, I, I, I, P]),
     "dh_cross_entropy_fwd": (I, [P, I, P, P, P, I, I, P]),
     "dh_cross_entropy_bwd": (I, [P, I, P, P, P, P, I, I, P]),
     "dh_engine_forward": (I, [P, P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), I, P, P, P]),
@@ -104,7 +107,7 @@ def load() -> C.CDLL:
             raise DualHypHipError(f"libdualhyp_hip.so does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.dh_abi_version() != 2:
+    if lib.dh_abi_version() != 3:
         raise DualHypHipError("libdualhyp_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -177,6 +177,9 @@ def save_checkpoint(model, path: Union[str, Path], lora_only: bool = False) -> N
     """`fabric.save(path, {"model": model})` (finetune/ger.py:356-358): the whole state dict under
     "model", reference keys.  `lora_only=True` applies `lora_filter` (what the reference imports at
     finetune/ger.py:26 but never uses) — a 18 MB file instead of 2.2 GB for TinyLlama."""
+    if getattr(model, "fp8", False):
+        raise RuntimeError("save_checkpoint: the model was quantised to fp8 (quantize_model_fp8); its state dict holds empty "
+                           "weights — save the bf16 model before quantising")
     sd = {k: v.detach().to("cpu") for k, v in model.state_dict().items() if not lora_only or "lora_" in k}
     Path(path).parent.mkdir(parents=True, exist_ok=True)
     torch.save({"model": sd}, str(path))

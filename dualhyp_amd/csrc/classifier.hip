@@ -59,7 +59,67 @@ __global__ __launch_bounds__(256) void pool_head_kernel(const bf16_t* __restrict
     }
 }
 
+// ---- training (finetune/relprompt.py:356-387: the mask cross entropy trains conv1 / conv2 / classifier) ----
+// backward of ReLU -> AvgPool1d(pool, ceil) -> Linear(H, 3) for one (b, window p) per block:
+//   pooled[bp][c] = bf16(mean_t relu(h[b][t][c]))                  (recomputed exactly as the forward does)
+//   dh[b][t][c]   = h[b][t][c] > 0 ? bf16((sum_j dl[bp][j] w[j][c]) / len) : 0
+__global__ __launch_bounds__(256) void pool_head_bwd_kernel(const bf16_t* __restrict__ h, const bf16_t* __restrict__ w,
+                                                            const float* __restrict__ dl, bf16_t* __restrict__ dh,
+                                                            bf16_t* __restrict__ pooled, int B, int T, int H, int pool, int P) {
+    const int bp = blockIdx.x, b = bp / P, p = bp % P;
+    const int t0 = p * pool, t1 = min(t0 + pool, T);
+    const float inv = 1.f / (float)(t1 - t0);
+    const float d0 = dl[(size_t)bp * 3], d1 = dl[(size_t)bp * 3 + 1], d2 = dl[(size_t)bp * 3 + 2];
+    for (int c = threadIdx.x; c < H; c += 256) {
+        float s = 0.f;
+        for (int t = t0; t < t1; ++t) s += fmaxf(bf2f(h[((size_t)b * T + t) * H + c]), 0.f);
+        pooled[(size_t)bp * H + c] = f2bf(s / (float)(t1 - t0));
+        const bf16_t g = f2bf((d0 * bf2f(w[c]) + d1 * bf2f(w[(size_t)H + c]) + d2 * bf2f(w[(size_t)2 * H + c])) * inv);
+        for (int t = t0; t < t1; ++t) {
+            const size_t i = ((size_t)b * T + t) * H + c;
+            dh[i] = bf2f(h[i]) > 0.f ? g : (bf16_t)0;
+        }
+    }
+}
+
+// backward of the k=3 im2col, fused with the ReLU (and dropout mask) that sits in front of it:
+//   dx[b][t][c] = [pre[b][t][c] > 0] * mask[b][t][c] * sum_dk dcol[b][t + 1 - dk][dk*C + c]     (rows outside 0..T-1 dropped)
+__global__ __launch_bounds__(256) void col2im3_kernel(const bf16_t* __restrict__ dcol, const bf16_t* __restrict__ pre,
+                                                      const bf16_t* __restrict__ mask, bf16_t* __restrict__ dx, int B, int T,
+                                                      int C, int ld) {
+    const int row = blockIdx.x, b = row / T, t = row % T;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+#pragma unroll
+        for (int dk = 0; dk < 3; ++dk) {
+            const int tr = t + 1 - dk;
+            if (tr >= 0 && tr < T) s += bf2f(dcol[((size_t)b * T + tr) * ld + dk * C + c]);
+        }
+        const size_t i = (size_t)row * C + c;
+        if (pre && !(bf2f(pre[i]) > 0.f)) s = 0.f;
+        if (mask) s *= bf2f(mask[i]);
+        dx[i] = f2bf(s);
+    }
+}
+
 }  // namespace
+
+extern "C" int dh_pool_head_bwd_bf16(const dh_bf16* h, const dh_bf16* w, const float* dlogits, dh_bf16* dh, dh_bf16* pooled,
+                                     int B, int T, int H, int pool, void* stream) {
+    DH_CHECK(h && w && dlogits && dh && pooled && B > 0 && T > 0 && H > 0 && pool > 0, "dh_pool_head_bwd_bf16: bad argument");
+    const int P = (T + pool - 1) / pool;
+    hipLaunchKernelGGL(pool_head_bwd_kernel, dim3(B * P), dim3(256), 0, (hipStream_t)stream, h, w, dlogits, dh, pooled, B, T, H, pool, P);
+    DH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dh_col2im3_bf16(const dh_bf16* dcol, const dh_bf16* pre, const dh_bf16* mask, dh_bf16* dx, int B, int T, int C,
+                               int ld, void* stream) {
+    DH_CHECK(dcol && dx && B > 0 && T > 0 && C > 0 && ld >= 3 * C, "dh_col2im3_bf16: bad argument");
+    hipLaunchKernelGGL(col2im3_kernel, dim3(B * T), dim3(256), 0, (hipStream_t)stream, dcol, pre, mask, dx, B, T, C, ld);
+    DH_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int dh_im2col3_bf16(const dh_bf16* x, dh_bf16* out, int B, int T, int C, int ld, int relu, void* stream) {
     DH_CHECK(x && out && B > 0 && T > 0 && C > 0, "dh_im2col3_bf16: bad argument");

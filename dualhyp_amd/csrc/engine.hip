@@ -202,10 +202,15 @@ int run_layers(dh_engine* e, const int64_t* ids, int n_tok, int n_seq, int max_q
     return 0;
 }
 
+// fp8 GEMM kernel by PHASE, never by packing (the two kernels sum K in different fp32 orders): a prefill is tiled even
+// when a short prompt runs alone; a single-token step streams the weights up to 128 rows (the bench's four batches per
+// decode loop) and is tiled above that — the one documented class boundary of the fp8 decode phase.
+inline int fp8_kernel(bool decode, int rows) { return decode && rows <= 128 ? 2 : 1; }
+
 // fp8 serving: the same layer sequence with every dense product on the fp8 MFMA (csrc/fp8.hip).  Activations are
 // quantised per token right where they are produced (the norm kernels) or by a pass over the attention / SwiGLU
 // output; LoRA is merged into the weights before quantisation, so there is no rank-16 side product.  Prefill and
-// decode run the same sequence; dh_linear_fp8 picks the weight-streaming kernel for <= 32 rows.
+// decode run the same sequence; the GEMM kernel is pinned by phase (fp8_kernel above).
 int run_layers_fp8(dh_engine* e, const int64_t* ids, int n_tok, int n_seq, int max_q_len, bool decode,
                    const uint8_t* tail_flags, hipStream_t s) {
     const uint8_t* rt = e->rsqrt_vec > 0 ? tail_flags : nullptr;
@@ -220,8 +225,8 @@ int run_layers_fp8(dh_engine* e, const int64_t* ids, int n_tok, int n_seq, int m
     // the weight pointers of dh_layer_weights address e4m3 bytes in this mode
     auto lin = [&](const bf16_t* w, const float* ws, bf16_t* y, int N, int K, int epi, const bf16_t* w2, const float* w2s,
                    const bf16_t* res) {
-        return dh_linear_fp8(e->xq, e->xscale, reinterpret_cast<const uint8_t*>(w), ws, y, n_tok, N, K, epi,
-                             reinterpret_cast<const uint8_t*>(w2), w2s, nullptr, nullptr, res, s);
+        return dh_linear_fp8_ex(e->xq, e->xscale, reinterpret_cast<const uint8_t*>(w), ws, y, n_tok, N, K, epi,
+                                reinterpret_cast<const uint8_t*>(w2), w2s, nullptr, nullptr, res, fp8_kernel(decode, n_tok), s);
     };
     if ((rc = dh_embed_bf16(ids, D.wte, e->x, n_tok, d, D.wte_rows, s))) return rc;
     for (int l = 0; l < D.n_layer; ++l) {
@@ -284,8 +289,9 @@ int head_fp8(dh_engine* e, const bf16_t* xrows, int rows, bf16_t* logits, const 
     if ((rc = dh_rmsnorm_quant_fp8(xrows, D.ln_f, e->xn, e->xq, e->xscale, rows, D.n_embd, D.norm_eps,
                                    e->rsqrt_vec > 0 ? rt : nullptr, s))) return rc;
     TimeScope t(e, e->phase_decode ? 1 : 0, s);
-    return dh_linear_fp8(e->xq, e->xscale, reinterpret_cast<const uint8_t*>(D.lm_head), D.lm_head_ws, logits, rows, D.vocab,
-                         D.n_embd, DH_EPI_ADAPTER, nullptr, nullptr, D.adapter_scale, D.adapter_bias, nullptr, s);
+    return dh_linear_fp8_ex(e->xq, e->xscale, reinterpret_cast<const uint8_t*>(D.lm_head), D.lm_head_ws, logits, rows, D.vocab,
+                            D.n_embd, DH_EPI_ADAPTER, nullptr, nullptr, D.adapter_scale, D.adapter_bias, nullptr,
+                            fp8_kernel(e->phase_decode, rows), s);
 }
 
 // K-slices of 8 (or 16 for long K) k-steps: the row-parallel streaming kernel (gemm_skinny.hip)

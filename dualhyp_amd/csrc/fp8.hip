@@ -577,7 +577,19 @@ extern "C" int dh_linear_fp8_f32(const uint8_t* xq, const float* x_scale, const 
 extern "C" int dh_linear_fp8(const uint8_t* xq, const float* x_scale, const uint8_t* wq, const float* w_scale, dh_bf16* y,
                              int M, int N, int K, int epilogue, const uint8_t* w2q, const float* w2_scale,
                              const dh_bf16* vec_a, const dh_bf16* vec_b, const dh_bf16* resid, void* stream) {
+    return dh_linear_fp8_ex(xq, x_scale, wq, w_scale, y, M, N, K, epilogue, w2q, w2_scale, vec_a, vec_b, resid, 0, stream);
+}
+
+// kernel: 0 = by row count (streaming up to FP8_STREAM_MAX_ROWS rows, tiled above), 1 = tiled, 2 = streaming.  The two
+// kernels add the K products in different fp32 orders (tiled: one sequential accumulator; streaming: K dealt round-robin
+// over 8 waves, partials summed through LDS), so a caller that wants a row's bits to be independent of what is packed
+// with it pins the kernel by PHASE (the engine: prefill tiled, single-token steps streaming up to 128 rows).
+extern "C" int dh_linear_fp8_ex(const uint8_t* xq, const float* x_scale, const uint8_t* wq, const float* w_scale, dh_bf16* y,
+                                int M, int N, int K, int epilogue, const uint8_t* w2q, const float* w2_scale,
+                                const dh_bf16* vec_a, const dh_bf16* vec_b, const dh_bf16* resid, int kernel, void* stream) {
     DH_CHECK(xq && x_scale && wq && w_scale && y, "dh_linear_fp8: null operand");
+    DH_CHECK(kernel >= 0 && kernel <= 2, "dh_linear_fp8: kernel %d (0 auto, 1 tiled, 2 streaming)", kernel);
+    DH_CHECK(kernel != 2 || M <= FP8_STREAM_MAX_ROWS, "dh_linear_fp8: the streaming kernel takes at most %d rows (M=%d)", FP8_STREAM_MAX_ROWS, M);
     DH_CHECK(M >= 0 && N > 0 && K > 0 && K % 128 == 0 && N % 4 == 0, "dh_linear_fp8: bad shape M=%d N=%d K=%d (K %% 128, N %% 4 must be 0)", M, N, K);
     DH_CHECK(epilogue == DH_EPI_PLAIN || epilogue == DH_EPI_SWIGLU || epilogue == DH_EPI_ADAPTER,
              "dh_linear_fp8: epilogue %d unsupported (LoRA is merged before quantisation)", epilogue);
@@ -586,7 +598,7 @@ extern "C" int dh_linear_fp8(const uint8_t* xq, const float* x_scale, const uint
     if (M == 0) return 0;
     Fp8Args a{xq, wq, w2q, y, x_scale, w_scale, w2_scale, vec_a, vec_b, resid, M, N, K, 0, 0};
     hipStream_t s = (hipStream_t)stream;
-    if (M <= FP8_STREAM_MAX_ROWS) {      // weight streaming: the decode step of up to four 32-row batches
+    if (kernel == 2 || (kernel == 0 && M <= FP8_STREAM_MAX_ROWS)) {      // weight streaming: the decode step of up to four 32-row batches
         switch (epilogue) {
             case DH_EPI_PLAIN: return launch_skinny<DH_EPI_PLAIN>(a, s);
             case DH_EPI_SWIGLU: return launch_skinny<DH_EPI_SWIGLU>(a, s);

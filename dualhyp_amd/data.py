@@ -136,12 +136,18 @@ def collate(samples: Sequence[Dict[str, Any]]) -> Dict[str, Any]:
 
     def pad(t: torch.Tensor, v: int) -> torch.Tensor:
         return torch.cat([t, torch.full((n - t.size(0),), v, dtype=t.dtype)])
-    return {"input_ids": torch.stack([pad(s["input_ids"], 0) for s in samples]),
-            "labels": torch.stack([pad(s["labels"], -1) for s in samples]),
-            "input_ids_no_response": [s["input_ids_no_response"] for s in samples],
-            "input": [s["input"] for s in samples],
-            "uid": [s.get("uid", "") for s in samples],
-            "ground_truth": [s.get("ground_truth", "") for s in samples]}
+    out = {"input_ids": torch.stack([pad(s["input_ids"], 0) for s in samples]),
+           "labels": torch.stack([pad(s["labels"], -1) for s in samples]),
+           "input_ids_no_response": [s.get("input_ids_no_response") for s in samples],
+           "input": [s.get("input", "") for s in samples],
+           "uid": [s.get("uid", "") for s in samples],
+           "ground_truth": [s.get("ground_truth", "") for s in samples]}
+    # RelPrompt fine-tune (finetune/relprompt.py:346-364): encoder features [T, C] and per-chunk reliability class
+    # indices ride along when an example carries them; like the reference's torch.stack they must agree in length
+    for k in ("audio_enc_features", "visual_enc_features", "audio_mask_targets", "visual_mask_targets"):
+        if all(k in s for s in samples):
+            out[k] = torch.stack([s[k] for s in samples])
+    return out
 
 
 class HypothesesDataset:
@@ -151,7 +157,8 @@ class HypothesesDataset:
 
     def __init__(self, json_path_or_items, tokenizer, prompts_format: str = "DualHyp", nhyps_key: str = "nhyps_asr",
                  max_nhyps: Optional[int] = None, max_input_length: int = 0, language: Optional[str] = None,
-                 mask_threshold: Optional[float] = None, time_window: float = 0.4, seed: Optional[int] = None) -> None:
+                 mask_threshold: Optional[float] = None, time_window: float = 0.4, seed: Optional[int] = None,
+                 enc_features=None) -> None:
         items = json_path_or_items
         if isinstance(items, (str, bytes)) or hasattr(items, "__fspath__"):
             with open(items, encoding="utf-8") as f:
@@ -160,6 +167,9 @@ class HypothesesDataset:
         for it in items:
             self.uid2sample.setdefault(it["Uid"], []).append(it)
         self.uids = list(self.uid2sample)
+        # RelPrompt fine-tune: callable (asr_item, vsr_item) -> (audio encoder features [T_a, whisper_dim], visual
+        # [T_v, raven_dim]); the Whisper / BRAVEn encoders themselves are upstream of this path (finetune/relprompt.py:346-352)
+        self.enc_features = enc_features
         self.tokenizer, self.fmt, self.nhyps_key = tokenizer, prompts_format, nhyps_key
         self.max_nhyps, self.max_input_length, self.language = max_nhyps, max_input_length, language
         self.mask_threshold = mask_threshold
@@ -184,4 +194,11 @@ class HypothesesDataset:
                 prompt = relprompt_prompt(s1, s2, al, vl, self.max_nhyps)
         ex = encode_example(self.tokenizer, prompt, s1["Caption"], self.max_input_length)
         ex["uid"], ex["ground_truth"] = s1.get("Uid", ""), s1.get("Caption", "")
+        if self.fmt == "RelPrompt":
+            # ground-truth reliability classes of the chunks (finetune/relprompt.py:73-79,364-365: <<C>> 0, <<M>> 1, else 2)
+            cls = {MASK_TOKENS[0]: 0, MASK_TOKENS[1]: 1}
+            ex["audio_mask_targets"] = torch.tensor([cls.get(l, 2) for l in al], dtype=torch.int64)
+            ex["visual_mask_targets"] = torch.tensor([cls.get(l, 2) for l in vl], dtype=torch.int64)
+            if self.enc_features is not None:
+                ex["audio_enc_features"], ex["visual_enc_features"] = self.enc_features(s1, s2)
         return ex

@@ -108,6 +108,10 @@ class TrainConfig:
     save_interval: int = 0               # micro-iterations between validations; 0 = only at the end
     reference_accumulation: bool = False
     shuffle: bool = True                 # False: utterances in file order (trajectory fixtures)
+    # RelPrompt (finetune/relprompt.py:625,641): the reliability classifiers train beside the LoRA parameters, in
+    # their own AdamW group with their own learning rate, on the mask cross entropy weighted by mask_loss_weight
+    classifier_learning_rate: float = 1e-4
+    mask_loss_weight: float = 0.02
 
 
 def micro_loss(model, input_ids: torch.Tensor, labels: torch.Tensor, chunk: int) -> torch.Tensor:
@@ -148,8 +152,18 @@ def fit(model, train_examples: Sequence[Dict[str, torch.Tensor]], collate: Calla
     from .train import prepare_for_training
     model.train()
     params = prepare_for_training(model)
-    opt = torch.optim.AdamW(params, lr=cfg.learning_rate, weight_decay=cfg.weight_decay)
-    bucket = FlatGradBucket(params)
+    # RelPrompt: the noise-mask classifiers stay trainable (ger/relprompt.py:79-119) and form the optimizer's second
+    # group with their own learning rate (finetune/relprompt.py:175-195); their gradients ride the same flat bucket
+    cls_params: List[torch.nn.Parameter] = []
+    if hasattr(model, "audio_noise_classifier"):
+        from .relprompt import prepare_classifiers_for_training
+        cls_params = prepare_classifiers_for_training(model)
+    groups = [{"params": params, "lr": cfg.learning_rate, "weight_decay": cfg.weight_decay}]
+    if cls_params:
+        groups.append({"params": cls_params, "lr": cfg.classifier_learning_rate, "weight_decay": cfg.weight_decay})
+    opt = torch.optim.AdamW(groups)
+    base_lrs = [cfg.learning_rate, cfg.classifier_learning_rate]
+    bucket = FlatGradBucket(params + cls_params)
     accum = max(cfg.batch_size // world // cfg.micro_batch_size, 1)
     epoch_size = len(train_examples) // cfg.micro_batch_size
     warmup = max(int(epoch_size * cfg.warmup_frac) // world, 1)
@@ -161,9 +175,15 @@ def fit(model, train_examples: Sequence[Dict[str, torch.Tensor]], collate: Calla
         for b0 in range(0, len(order) - cfg.micro_batch_size + 1, cfg.micro_batch_size):
             batch = collate([train_examples[i] for i in order[b0:b0 + cfg.micro_batch_size]])
             ids, labels = batch["input_ids"].to(device), batch["labels"].to(device)
-            for g in opt.param_groups:
-                g["lr"] = lr_at(it, cfg.learning_rate, warmup, max_iters, cfg.use_cosine_scheduler, cfg.min_lr_ratio)
+            for g, base in zip(opt.param_groups, base_lrs):       # both groups follow the same schedule (relprompt.py:321-341)
+                g["lr"] = lr_at(it, base, warmup, max_iters, cfg.use_cosine_scheduler, cfg.min_lr_ratio)
             loss = micro_loss(model, ids, labels, cfg.lm_head_chunk_size)
+            if cls_params and "audio_enc_features" in batch and "audio_mask_targets" in batch:
+                from .relprompt import mask_loss                   # finetune/relprompt.py:356-403
+                a_lg = model.audio_noise_classifier(batch["audio_enc_features"].to(device))
+                v_lg = model.visual_noise_classifier(batch["visual_enc_features"].to(device))
+                loss = loss + cfg.mask_loss_weight * mask_loss(a_lg, v_lg, batch["audio_mask_targets"].to(device),
+                                                               batch["visual_mask_targets"].to(device))
             (loss / accum).backward()
             loss_acc += loss.detach()
             if on_micro is not None:
@@ -176,7 +196,7 @@ def fit(model, train_examples: Sequence[Dict[str, torch.Tensor]], collate: Calla
                 bucket.zero()
                 model.refresh_engine()
                 if on_step is not None:
-                    on_step(steps, params)
+                    on_step(steps, params + cls_params)
                 micro, steps = 0, steps + 1
             it += 1
             if cfg.save_interval and it % cfg.save_interval == 0:
@@ -246,6 +266,15 @@ def main(argv: Optional[Sequence[str]] = None) -> Dict[str, float]:
     p.add_argument("--out_dir", type=str, default=None, help="default ./runs/<exp_name>")
     p.add_argument("--reference_accumulation", action="store_true", help="quirk Q3: step every batch_size-1 micro-batches")
     p.add_argument("--seed", type=int, default=1337)
+    # finetune/relprompt.py:625,641-643 (RelPrompt: the reliability classifiers train in a second AdamW group)
+    p.add_argument("--classifier_lr", type=float, default=1e-4)
+    p.add_argument("--mask_loss_weight", type=float, default=0.02)
+    p.add_argument("--mask_threshold", type=int, default=None)
+    p.add_argument("--time_window", type=float, default=0.4)
+    p.add_argument("--pool_size", type=int, default=10)
+    p.add_argument("--enc_features_dir", type=str, default=None,
+                   help="addition of this build: <dir>/<Uid>.pt = {'audio': [T, whisper_dim], 'visual': [T, raven_dim]} encoder features "
+                        "(the Whisper / BRAVEn encoders of finetune/relprompt.py:346-352 are upstream of this path)")
     args = p.parse_args(argv)
     if args.apply_chat_template:
         raise NotImplementedError("--apply_chat_template is outside the hot path")
@@ -269,14 +298,28 @@ def main(argv: Optional[Sequence[str]] = None) -> Dict[str, float]:
     if tc_path.is_file():
         max_input_length = json.loads(tc_path.read_text()).get("model_max_length") or 1024
     max_input_length = min(int(max_input_length), cfg.block_size)
-    model = GPT(cfg)
+    rel = args.prompts_format == "RelPrompt"
+    if rel:                                                # finetune/relprompt.py:141-147: classifiers + 3 reliability tokens
+        from .relprompt import GPT as RelGPT
+        cfg.pool_size = args.pool_size
+        model = RelGPT(cfg)
+    else:
+        model = GPT(cfg)
     if args.random_init:
         from .synth import synth_state_dict
-        model.load_state_dict(synth_state_dict(cfg, seed=args.seed), strict=True)
+        model.load_state_dict(synth_state_dict(cfg, seed=args.seed), strict=not rel)
     else:
         model.load_state_dict(load_checkpoint(Path(args.llm_checkpoint) / "lit_model.pth"), strict=False)   # LoRA tensors keep their init
+    if rel:
+        tokenizer.add_reliability_tokens(cfg.padded_vocab_size)
+        model.resize_token_embeddings(3)
     model = model.to(device=dev, dtype=torch.bfloat16)
-    fmt = args.prompts_format if (args.dual_hypotheses or args.prompts_format == "RelPrompt") else "GER"
+    fmt = args.prompts_format if (args.dual_hypotheses or rel) else "GER"
+    enc_features = None
+    if rel and args.enc_features_dir:
+        def enc_features(s1, s2, _d=Path(args.enc_features_dir)):
+            f = torch.load(_d / f"{s1['Uid']}.pt", map_location="cpu")
+            return f["audio"].float(), f["visual"].float()
 
     def dataset(path, seed):
         items = []
@@ -284,7 +327,8 @@ def main(argv: Optional[Sequence[str]] = None) -> Dict[str, float]:
             with open(one, encoding="utf-8") as f:
                 items += json.load(f)
         return HypothesesDataset(items, tokenizer, prompts_format=fmt, nhyps_key=args.nhyps_key, max_nhyps=args.max_nhyps,
-                                 max_input_length=max_input_length, language=args.language, seed=seed)
+                                 max_input_length=max_input_length, language=args.language, seed=seed,
+                                 mask_threshold=args.mask_threshold, time_window=args.time_window, enc_features=enc_features)
     train_ds = dataset(args.train_path, args.seed + rank)
     train = [train_ds[i] for i in range(len(train_ds))]
     val_batches = None
@@ -299,7 +343,8 @@ def main(argv: Optional[Sequence[str]] = None) -> Dict[str, float]:
     tc = TrainConfig(learning_rate=args.lr, weight_decay=args.weight_decay, num_epochs=args.num_epochs, batch_size=args.batch_size,
                      micro_batch_size=args.micro_batch_size, warmup_frac=args.wp, use_cosine_scheduler=args.use_cosine_scheduler,
                      min_lr_ratio=args.min_lr_ratio, save_interval=max(args.save_interval // world, 1),
-                     reference_accumulation=args.reference_accumulation)
+                     reference_accumulation=args.reference_accumulation, classifier_learning_rate=args.classifier_lr,
+                     mask_loss_weight=args.mask_loss_weight)
     log = logging.info if rank == 0 else (lambda s: None)
     t0 = time.perf_counter()
     out = fit(model, train, collate, tc, val_batches=val_batches, out_dir=str(out_dir), rank=rank, world=world, device=dev, log=log)

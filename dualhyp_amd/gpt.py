@@ -445,6 +445,9 @@ class GPT(nn.Module):
 
     def load_state_dict(self, state_dict, strict: bool = True, assign: bool = False):
         # accept both 'x.linear.weight' (reference key) and our holder's 'x.linear.weight' (identical)
+        if getattr(self, "fp8", False):
+            raise RuntimeError("load_state_dict: this model was quantised to fp8 (quantize_model_fp8): its bf16 weights no longer "
+                               "exist; load the checkpoint into a fresh GPT and quantise that")
         out = super().load_state_dict(state_dict, strict=strict, assign=assign)
         self._drop_engine()
         return out

@@ -110,13 +110,14 @@ def init_distributed(n_devices: int):
     import sys
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if "WORLD_SIZE" not in os.environ and n_devices > 1:
-        import socket
         import subprocess
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_devices}", "--master-addr",
-               "127.0.0.1", "--master-port", str(port), "-m", sys.modules["__main__"].__spec__.name, *sys.argv[1:]]
+        # --standalone lets the launcher pick (and hold) its own rendezvous port on 127.0.0.1: no bind/close race.  The
+        # target is this run's entry point: `-m package.module` when started that way, else the script path
+        # (__main__.__spec__ is None for `python dualhyp_amd/finetune.py` or when called from another entry point)
+        spec = getattr(sys.modules.get("__main__"), "__spec__", None)
+        target = ["-m", spec.name] if spec is not None and spec.name else [os.path.abspath(sys.argv[0])]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+               f"--nproc-per-node={n_devices}", *target, *sys.argv[1:]]
         sys.exit(subprocess.run(cmd).returncode)
     rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     rehearsal = os.environ.get("DUALHYP_DP_REHEARSAL") == "1"    # every rank on cuda:0, gloo (one-GPU boxes, tests)

@@ -203,17 +203,18 @@ def rmsnorm_quant_fp8(x: torch.Tensor, w: torch.Tensor, eps: float, row_tail: Op
 
 def linear_fp8(xq: torch.Tensor, x_scale: torch.Tensor, wq: torch.Tensor, w_scale: torch.Tensor, *, epilogue: int = EPI_PLAIN,
                w2q: Optional[torch.Tensor] = None, w2_scale: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
-               bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """bf16 [M, N] = epilogue((xq . wq^T) * x_scale[m] * w_scale[n]) on the fp8 MFMA; dh_linear_fp8."""
+               bias: Optional[torch.Tensor] = None, resid: Optional[torch.Tensor] = None, kernel: int = 0) -> torch.Tensor:
+    """bf16 [M, N] = epilogue((xq . wq^T) * x_scale[m] * w_scale[n]) on the fp8 MFMA; dh_linear_fp8_ex (kernel: 0 by row
+    count, 1 tiled, 2 streaming)."""
     k = _Keep()
     M, K = xq.shape
     N = wq.size(0)
     assert wq.size(1) == K and xq.dtype == torch.uint8 and wq.dtype == torch.uint8
     y = torch.empty((M, N), dtype=torch.bfloat16, device=xq.device)
-    check(_lib.load().dh_linear_fp8(k(xq, torch.uint8, "xq"), k(x_scale, torch.float32, "x_scale"), k(wq, torch.uint8, "wq"),
-                                    k(w_scale, torch.float32, "w_scale"), _p(y), M, N, K, epilogue, k(w2q, torch.uint8, "w2q"),
-                                    k(w2_scale, torch.float32, "w2_scale"), k(scale, name="scale"), k(bias, name="bias"),
-                                    k(resid, name="resid"), _stream()))
+    check(_lib.load().dh_linear_fp8_ex(k(xq, torch.uint8, "xq"), k(x_scale, torch.float32, "x_scale"), k(wq, torch.uint8, "wq"),
+                                       k(w_scale, torch.float32, "w_scale"), _p(y), M, N, K, epilogue, k(w2q, torch.uint8, "w2q"),
+                                       k(w2_scale, torch.float32, "w2_scale"), k(scale, name="scale"), k(bias, name="bias"),
+                                       k(resid, name="resid"), int(kernel), _stream()))
     return y
 
 
@@ -235,6 +236,31 @@ def pool_head(h: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, pool: int) -
     check(_lib.load().dh_pool_head_bf16(_p(h), k(w, name="w"), k(bias, name="bias"), _p(out), B, T, H, int(pool),
                                         _stream()))
     return out
+
+
+def pool_head_bwd(h: torch.Tensor, w: torch.Tensor, dlogits: torch.Tensor, pool: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(dh bf16 [B,T,H], pooled bf16 [B*P,H]) from dlogits fp32 [B,P,3]; dh_pool_head_bwd_bf16."""
+    k = _Keep()
+    h = _dev(h, name="h")
+    B, T, H = h.shape
+    P = (T + pool - 1) // pool
+    assert dlogits.shape == (B, P, 3)
+    dh = torch.empty_like(h)
+    pooled = torch.empty((B * P, H), dtype=torch.bfloat16, device=h.device)
+    check(_lib.load().dh_pool_head_bwd_bf16(_p(h), k(w, name="w"), k(dlogits, torch.float32, "dlogits"), _p(dh), _p(pooled),
+                                            B, T, H, int(pool), _stream()))
+    return dh, pooled
+
+
+def col2im3(dcol: torch.Tensor, B: int, T: int, C: int, pre: Optional[torch.Tensor] = None,
+            mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dx bf16 [B,T,C]: backward of im2col3 through the ReLU of `pre` and the dropout `mask` in front of it; dh_col2im3_bf16."""
+    k = _Keep()
+    dcol = _dev(dcol, name="dcol")
+    assert dcol.dim() == 2 and dcol.size(0) == B * T and dcol.size(1) >= 3 * C
+    dx = torch.empty((B, T, C), dtype=torch.bfloat16, device=dcol.device)
+    check(_lib.load().dh_col2im3_bf16(_p(dcol), k(pre, name="pre"), k(mask, name="mask"), _p(dx), B, T, C, dcol.size(1), _stream()))
+    return dx
 
 
 def cross_entropy_fwd(logits: torch.Tensor, targets: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -39,6 +39,9 @@ def dequantize_rows_fp8(q: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
 
 
 def quantize_model_fp8(model) -> None:
+    """Serving-only, one way: merge LoRA, replace every dense weight by e4m3 rows + channel scales (non-persistent
+    buffers).  The bf16 weights are gone afterwards, so `GPT.load_state_dict` and `save_checkpoint` refuse a quantised
+    model (quantise a freshly loaded model instead)."""
     from .gpt import GPT, _FrozenLinear, merge_lora_weights
     assert isinstance(model, GPT)
     if getattr(model, "fp8", False):

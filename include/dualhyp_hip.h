@@ -26,7 +26,7 @@ extern "C" {
 
 typedef uint16_t dh_bf16;
 
-#define DH_ABI_VERSION 2
+#define DH_ABI_VERSION 3
 
 int dh_abi_version(void);
 /* Kernel-variant selector for A/B measurements inside one process (bench.py --tune k=v); never needed in production,
@@ -225,6 +225,17 @@ int dh_im2col3_bf16(const dh_bf16* x, dh_bf16* out, int B, int T, int C, int ld,
  * Linear(H -> 3): h [B,T,H] pre-activation, w [3,H], bias [3], out [B, ceil(T/pool), 3]. */
 int dh_pool_head_bf16(const dh_bf16* h, const dh_bf16* w, const dh_bf16* bias, dh_bf16* out, int B, int T,
                       int H, int pool, void* stream);
+/* Training of the reliability predictors — finetune/relprompt.py:356-387 (the mask cross entropy back-propagates
+ * into conv1 / conv2 / classifier; ger/relprompt.py:79-119 keeps them trainable).
+ * dh_pool_head_bwd_bf16: backward of ReLU -> AvgPool1d(pool, ceil) -> Linear(H, 3): dlogits fp32 [B, P, 3] ->
+ *   dh bf16 [B,T,H] (gradient of the PRE-activation h) and pooled bf16 [B*P, H] (the Linear's input, recomputed
+ *   exactly as dh_pool_head_bf16 forms it; the caller contracts it with dlogits for the Linear's weight gradient).
+ * dh_col2im3_bf16: backward of dh_im2col3_bf16 fused with what precedes it: dx[b,t,c] = [pre[b,t,c] > 0] *
+ *   mask[b,t,c] * sum_dk dcol[b, t+1-dk, dk*C + c]; pre (ReLU input) and mask (scaled dropout mask) may be NULL. */
+int dh_pool_head_bwd_bf16(const dh_bf16* h, const dh_bf16* w, const float* dlogits, dh_bf16* dh, dh_bf16* pooled,
+                          int B, int T, int H, int pool, void* stream);
+int dh_col2im3_bf16(const dh_bf16* dcol, const dh_bf16* pre, const dh_bf16* mask, dh_bf16* dx, int B, int T, int C,
+                    int ld, void* stream);
 
 /* One decode-loop tail per sequence — generate/base.py:62-80:
  *   l = logits/temperature (bf16) ; keep l >= k-th largest ; softmax ; multinomial.
@@ -259,6 +270,12 @@ int dh_rmsnorm_quant_fp8(const dh_bf16* x, const dh_bf16* w, dh_bf16* xn_out, ui
 int dh_linear_fp8(const uint8_t* xq, const float* x_scale, const uint8_t* wq, const float* w_scale, dh_bf16* y, int M, int N,
                   int K, int epilogue, const uint8_t* w2q, const float* w2_scale, const dh_bf16* vec_a, const dh_bf16* vec_b,
                   const dh_bf16* resid, void* stream);
+/* dh_linear_fp8 with the kernel pinned: 0 = by row count (as above), 1 = tiled, 2 = streaming (M <= 128).  The two kernels
+ * add the K products in different fp32 orders; the engine pins by PHASE (prefill tiled whatever the packing, single-token
+ * steps streaming up to 128 rows) so that a sequence's bits do not depend on what is packed with it. */
+int dh_linear_fp8_ex(const uint8_t* xq, const float* x_scale, const uint8_t* wq, const float* w_scale, dh_bf16* y, int M, int N,
+                     int K, int epilogue, const uint8_t* w2q, const float* w2_scale, const dh_bf16* vec_a, const dh_bf16* vec_b,
+                     const dh_bf16* resid, int kernel, void* stream);
 
 /* dh_linear_fp8 PLAIN for 1 <= M <= 32 with the bf16-rounded result written as fp32 [M, N]: the single "partial" the
  * fused decode-attention kernel (dh_attn_decode_fused_bf16, n_part = 1, no LoRA) consumes. */

@@ -51,7 +51,7 @@ def test_row_quantisation_is_the_oracles():
     assert torch.equal(one[0][0], many[0][7]) and torch.equal(one[1][0], many[1][7]) and torch.equal(one[2], many[2][7:8])
 
 
-@pytest.mark.parametrize("M", [1, 19, 32, 33, 200])
+@pytest.mark.parametrize("M", [1, 19, 32, 33, 96, 128, 200])
 def test_fp8_mfma_operand_map_exact_integers(M):
     """Values in {-1, 0, 1} placed by an asymmetric rule in (row, k): every product and partial sum is exact, so any
     wrong lane -> (row, k) assumption of v_mfma_scale_f32_16x16x128_f8f6f4 shows as a wrong integer."""
@@ -64,14 +64,21 @@ def test_fp8_mfma_operand_map_exact_integers(M):
     w[:, ::5] = -1.0
     xq, wq = x.to(torch.float8_e4m3fn).view(torch.uint8), w.to(torch.float8_e4m3fn).view(torch.uint8)
     ones_m, ones_n = torch.ones(M), torch.ones(N)
-    y = ops.linear_fp8(xq.to(DEV), ones_m.to(DEV), wq.to(DEV), ones_n.to(DEV))
     want = x @ w.T
     assert want.abs().max() <= 256
-    assert torch.equal(y.float().cpu(), want), f"fp8 GEMM (M={M}) is not the exact integer product"
+    # every kernel that can take this row count: streaming (NG = 1, 2, 4 row groups: M <= 32 / 64 / 128) and tiled
+    for kernel in (0, 1, 2):
+        if kernel == 2 and M > 128:
+            continue
+        y = ops.linear_fp8(xq.to(DEV), ones_m.to(DEV), wq.to(DEV), ones_n.to(DEV), kernel=kernel)
+        assert torch.equal(y.float().cpu(), want), f"fp8 GEMM (M={M}, kernel={kernel}) is not the exact integer product"
 
 
-@pytest.mark.parametrize("M,N,K", [(7, 512, 512), (32, 2560, 2048), (40, 256, 384), (300, 2560, 2048), (130, 1024, 4096), (257, 512, 1792)])
+@pytest.mark.parametrize("M,N,K", [(7, 512, 512), (32, 2560, 2048), (40, 256, 384), (96, 1024, 2048), (128, 2560, 4096), (300, 2560, 2048),
+                                   (130, 1024, 4096), (257, 512, 1792)])
 def test_linear_fp8_matches_the_oracle(M, N, K):
+    """Streaming kernel: M <= 32 (NG 1), <= 64 (NG 2), 65..128 (NG 4: the bench's 4 x 32-row decode step); tiled above.
+    Up to 128 rows BOTH kernels are checked (the engine pins tiled for a prefill of any size)."""
     from dualhyp_amd import ops
     from oracle import ger_oracle as O
     x, w, w2 = U((M, K), 1.5, "fx"), U((N, K), 0.05, "fw"), U((N, K), 0.05, "fw2")
@@ -90,14 +97,24 @@ def test_linear_fp8_matches_the_oracle(M, N, K):
         record_parity(f"fp8_linear.{what}.M{M}N{N}K{K}", max_ulp=u.max().item(), bit_exact_frac=1.0 - f)
         assert u.max().item() <= max_ulp and f <= max_frac, f"{what}: max {u.max().item()} ulp, {f:.3%} differ"
     y0 = O.linear_fp8(x, wq, ws.view(-1))
-    chk(ops.linear_fp8(xq, xs, wqd, wsd), y0, "plain")
     r = U((M, N), 1.0, "fr")
-    chk(ops.linear_fp8(xq, xs, wqd, wsd, resid=dv(r)), r + y0, "resid", floor=1.0)   # a sum of two O(rms) terms
     F = torch.nn.functional
-    chk(ops.linear_fp8(xq, xs, wqd, wsd, epilogue=ops.EPI_SWIGLU, w2q=w2qd, w2_scale=w2sd), F.silu(y0) * O.linear_fp8(x, w2q, w2s.view(-1)), "swiglu",
-        max_ulp=4, max_frac=0.025)      # a product of two rounded values: their boundary flips add up
     sc, bi = (1 + U((N,), 0.5, "fs").float()).bfloat16(), U((N,), 0.5, "fb")
-    chk(ops.linear_fp8(xq, xs, wqd, wsd, epilogue=ops.EPI_ADAPTER, scale=dv(sc), bias=dv(bi)), sc * (y0 + bi), "adapter", floor=1.0, max_ulp=4)    # y0 + bias cancels: ulps at max(|a|, |b|, rms)
+    for kernel, tag in ((2, "stream."), (1, "tiled.")) if M <= 128 else ((0, ""),):
+        chk(ops.linear_fp8(xq, xs, wqd, wsd, kernel=kernel), y0, tag + "plain")
+        chk(ops.linear_fp8(xq, xs, wqd, wsd, resid=dv(r), kernel=kernel), r + y0, tag + "resid", floor=1.0)   # a sum of two O(rms) terms
+        chk(ops.linear_fp8(xq, xs, wqd, wsd, epilogue=ops.EPI_SWIGLU, w2q=w2qd, w2_scale=w2sd, kernel=kernel),
+            F.silu(y0) * O.linear_fp8(x, w2q, w2s.view(-1)), tag + "swiglu", max_ulp=4, max_frac=0.025)      # a product of two rounded values: their boundary flips add up
+        chk(ops.linear_fp8(xq, xs, wqd, wsd, epilogue=ops.EPI_ADAPTER, scale=dv(sc), bias=dv(bi), kernel=kernel), sc * (y0 + bi), tag + "adapter",
+            floor=1.0, max_ulp=4)    # y0 + bias cancels: ulps at max(|a|, |b|, rms)
+    if M <= 128:
+        # a row's bits do not depend on how many rows ride along, inside either kernel (1 row vs all M, across the
+        # 32- and 64-row group boundaries of the streaming kernel)
+        for kernel in (1, 2):
+            full = ops.linear_fp8(xq, xs, wqd, wsd, kernel=kernel)
+            for rows in {1, min(M, 33), min(M, 65)}:
+                part = ops.linear_fp8(xq[:rows].contiguous(), xs[:rows].contiguous(), wqd, wsd, kernel=kernel)
+                assert torch.equal(part, full[:rows]), f"kernel {kernel}: rows 0..{rows} depend on the row count ({M} vs {rows})"
 
 
 def rel_rms(a, b):
@@ -162,10 +179,15 @@ def test_fp8_decoder_vs_oracle_restatement():
     alone = [generate(m, p, p.numel() + 5, temperature=0.2, top_k=1).cpu() for p in (p0, p1)]
     both = [o.cpu() for o in generate_batch(m, [p0, p1], 5, temperature=0.2, top_k=1)]
     assert all(torch.equal(a, b) for a, b in zip(alone, both))
-    # 40 prompts in one joint decode: > 32 rows takes the tiled fp8 kernel; same ids as alone
-    many = [idx[1].to(DEV)] * 40
-    joint = generate_batch(m, many, 5, temperature=0.2, top_k=1, prefill_batch=16)
-    assert all(torch.equal(o.cpu(), alone[1]) for o in joint)
+    # joint decodes of 33 (streaming NG 2, just past the 32-row fused-attention launch), 40 and 128 prompts (NG 4: the
+    # llama3-8b-fp8 bench's four batches per decode loop): same ids as the prompt alone.  The prefill is tiled whatever
+    # the packing (a 40-token prompt alone, 16 of them packed), the decode streams up to 128 rows: kernels are pinned
+    # by phase, csrc/engine.hip fp8_kernel
+    for n, pb in ((33, 33), (40, 16), (128, 32)):
+        joint = generate_batch(m, [idx[1].to(DEV)] * n, 5, temperature=0.2, top_k=1, prefill_batch=pb)
+        assert all(torch.equal(o.cpu(), alone[1]) for o in joint), f"{n}-row joint decode differs from the alone run"
+    mixed = generate_batch(m, [p0, p1] * 48, 5, temperature=0.2, top_k=1, prefill_batch=32)      # 96 ragged rows
+    assert all(torch.equal(o.cpu(), alone[i % 2]) for i, o in enumerate(mixed))
 
 
 def test_fp8_llama3_shape_vs_reference(golden):

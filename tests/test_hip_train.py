@@ -161,7 +161,7 @@ def test_train_micro_step_matches_reference(golden, name):
     loss = chunked_cross_entropy(logits, labels[..., 1:], chunk_size=8)
     (loss / 32).backward()
     ref_loss, f32_loss = t["bf16.train_loss"].float().item(), t["fp32.train_loss"].item()
-    assert abs(loss.item() - f32_loss) <= max(2 * abs(ref_loss - f32_loss), 2e-2), (loss.item(), ref_loss, f32_loss)
+    assert abs(loss.item() - f32_loss) <= max(1.3 * abs(ref_loss - f32_loss), 5e-3), (loss.item(), ref_loss, f32_loss)
     worst = 0.0
     for n, p in m.named_parameters():
         if "lora_" not in n:
@@ -173,8 +173,8 @@ def test_train_micro_step_matches_reference(golden, name):
         scale = g32.abs().max().item()
         e_hip, e_ref = (got - g32).abs().max().item() / scale, (gbf - g32).abs().max().item() / scale
         worst = max(worst, e_hip)
-        # HIP's distance to the exact (fp32) gradient within 2x the reference-bf16 run's own, or 3% of max
-        assert e_hip <= max(2.0 * e_ref, 0.03), f"{n}: hip {e_hip:.3f} vs reference-bf16 {e_ref:.3f} of max|g|"
+        # HIP's distance to the exact (fp32) gradient within 1.3x the reference-bf16 run's own, or 2% of max
+        assert e_hip <= max(1.3 * e_ref, 0.02), f"{n}: hip {e_hip:.3f} vs reference-bf16 {e_ref:.3f} of max|g|"
     record_parity(f"{name}.lora_grads", worst_dist_to_fp32_over_max_g=worst, loss=loss.item(), ref_loss_bf16=ref_loss, ref_loss_fp32=f32_loss)
     # eval-mode forward under no_grad still goes through the engine
     m.eval()
@@ -275,7 +275,7 @@ def test_train_micro_step_tinyllama_shape(golden):
     loss = chunked_cross_entropy(logits, labels[..., 1:], chunk_size=128)
     (loss / meta["grad_accum"]).backward()
     l32, lbf, lmx = (t[f"{k}.train_loss"].float().item() for k in ("fp32", "bf16", "mixed"))
-    assert abs(loss.item() - l32) <= max(2 * abs(lbf - l32), 2 * abs(lmx - l32), 5e-3), (loss.item(), l32, lbf, lmx)
+    assert abs(loss.item() - l32) <= max(1.3 * abs(lbf - l32), 1.3 * abs(lmx - l32), 1e-3), (loss.item(), l32, lbf, lmx)
     worst = {"hip": 0.0, "bf16": 0.0, "mixed": 0.0}
     for n, p in m.named_parameters():
         if "lora_" not in n:
@@ -287,7 +287,8 @@ def test_train_micro_step_tinyllama_shape(golden):
              "mixed": (t[f"mixed.grad.{n}"].float() - g32).abs().max().item() / scale}
         for k in worst:
             worst[k] = max(worst[k], e[k])
-        assert e["hip"] <= max(2.0 * max(e["bf16"], e["mixed"]), 0.03), f"{n}: {e}"
+        assert e["hip"] <= max(1.3 * max(e["bf16"], e["mixed"]), 0.02), f"{n}: {e}"
+    assert worst["hip"] <= 1.3 * max(worst["bf16"], worst["mixed"]), worst      # 2x -> 1.3x (measured 1.02x)
     record_parity("train_tinyllama_shape.lora_grads", loss_hip=loss.item(), loss_fp32=l32, loss_bf16=lbf, loss_mixed=lmx,
                   worst_hip=worst["hip"], worst_ref_bf16=worst["bf16"], worst_ref_mixed=worst["mixed"])
 
@@ -338,4 +339,112 @@ def test_adamw_trajectory_matches_reference(golden):
         rh, rm = (num_h / den) ** 0.5, (num_m / den) ** 0.5
         record_parity(f"adamw_tiny.step{step}", rel_rms_hip_vs_fp32=rh, rel_rms_mixed_vs_fp32=rm, loss_hip=losses[2 * step + 1],
                       loss_fp32=l32[2 * step + 1].item())
-        assert rh <= max(2.0 * rm, 0.1), f"step {step}: HIP parameters {rh:.3f} of the update away from the fp32 trajectory, bf16-mixed {rm:.3f}"
+        assert rh <= max(1.3 * rm, 0.02), f"step {step}: HIP parameters {rh:.3f} of the update away from the fp32 trajectory, bf16-mixed {rm:.3f}"
+
+
+def test_noise_mask_classifier_training():
+    """SURVEY §8f-3, training half (finetune/relprompt.py:356-387): the mask cross entropy and the gradients of all six
+    NoiseMaskClassifier parameters on the HIP path against what the REFERENCE module's autograd produced
+    (tests/golden/noise_mask_classifier: ger/relprompt.py:126-147 in fp32, in bf16 and under bf16 autocast with fp32
+    parameters).  HIP keeps activations in bf16 and accumulates parameter gradients in fp32: per parameter its distance
+    to the fp32 gradient must stay within 1.3x the larger of the reference's own bf16 / bf16-mixed distances."""
+    import torch.nn.functional as F
+    from conftest import load_golden
+    from dualhyp_amd.relprompt import NoiseMaskClassifier
+    t, meta = load_golden("noise_mask_classifier")
+    for tag, mt in meta.items():
+        C, pool, T = mt["C"], mt["pool"], mt["T"]
+        m = NoiseMaskClassifier(C, pool_size=pool).eval()             # eval: the fixture has no dropout draw
+        sd = {k: uniform(tuple(shape), 1.0 / math.sqrt(math.prod(shape[1:]) if len(shape) > 1 else 256.0), stream_id(mt["seed"], tag + k)).float()
+              for k, shape in mt["shapes"].items()}
+        m.load_state_dict(sd)
+        m = m.to(DEV)
+        x = uniform((2, T, C), 1.5, stream_id(mt["seed"], tag + "x")).to(DEV)
+        logits = m(x)
+        assert logits.requires_grad and logits.shape == (2, (T + pool - 1) // pool, 3)
+        with torch.no_grad():
+            assert torch.equal(logits.detach(), m(x)), "the differentiable forward must produce the inference path's bits"
+        loss = F.cross_entropy(logits.float().view(-1, 3), t[f"{tag}.targets"].to(DEV).view(-1))
+        loss.backward()
+        l32, lbf, lmx = (t[f"{tag}.{k}.loss"].item() for k in ("fp32", "bf16", "mixed"))
+        assert abs(loss.item() - l32) <= max(1.3 * abs(lbf - l32), 1.3 * abs(lmx - l32), 1e-3), (loss.item(), l32, lbf, lmx)
+        worst = {}
+        for k, p in m.named_parameters():
+            g = p.grad.float().cpu()
+            assert g.shape == p.shape
+            if g.dim() == 3:
+                stat = t[f"{tag}.fp32.gradstat.{k}"]
+                assert abs(g.norm().item() - stat[1].item()) <= 0.05 * stat[1].item(), (k, g.norm().item(), stat[1].item())
+                scale, g = stat[0].item(), g[::16]
+            else:
+                scale = t[f"{tag}.fp32.grad.{k}"].abs().max().item()
+            g32 = t[f"{tag}.fp32.grad.{k}"]
+            e = {"hip": (g - g32).abs().max().item() / scale,
+                 "bf16": (t[f"{tag}.bf16.grad.{k}"] - g32).abs().max().item() / scale,
+                 "mixed": (t[f"{tag}.mixed.grad.{k}"] - g32).abs().max().item() / scale}
+            worst[k] = e
+            assert e["hip"] <= max(1.3 * max(e["bf16"], e["mixed"]), 5e-3), f"{tag}.{k}: {e}"
+        record_parity(f"classifier_training.{tag}", loss_hip=loss.item(), loss_fp32=l32, loss_bf16=lbf, loss_mixed=lmx,
+                      **{f"{k}.{w}": v for k, e in worst.items() for w, v in e.items()})
+
+
+def test_fit_trains_relprompt_classifiers():
+    """finetune/relprompt.py:175-195,356-403 through `fit`: the reliability classifiers are the optimizer's second
+    group with their own learning rate, trained on 0.02 x (audio + visual mask cross entropy) added to the LM loss."""
+    from dualhyp_amd import Config
+    from dualhyp_amd.data import collate
+    from dualhyp_amd.finetune import TrainConfig, fit, micro_loss
+    from dualhyp_amd.relprompt import GPT as RelGPT, mask_loss
+    from dualhyp_amd.synth import synth_state_dict, hash_u24, stream_id
+    cfg = Config.from_name("parity-tiny", r=4, alpha=8, dropout=0.0, to_query=True, to_key=True, to_value=True, to_projection=True)
+    cfg.whisper_dim, cfg.raven_dim, cfg.pool_size = 64, 32, 2
+
+    def fresh():
+        torch.manual_seed(3)
+        m = RelGPT(cfg)
+        m.load_state_dict(synth_state_dict(cfg, seed=5, weight_scale=4.0), strict=False)
+        m.resize_token_embeddings(3)
+        return m.to(device=DEV, dtype=torch.bfloat16)
+
+    exs = []
+    for i in range(8):
+        T = 20 + i % 3
+        ids = (hash_u24(T, stream_id(9, f"rp{i}")) % 200 + 3)
+        lab = ids.clone()
+        lab[:-6] = -1
+        Ta, Tv = 16, 8                                      # 50 fps / 25 fps features; pools 4 and 2 -> 4 chunks each
+        exs.append({"input_ids": ids, "labels": lab,
+                    "audio_enc_features": uniform((Ta, 64), 1.0, stream_id(9, f"a{i}")).float(),
+                    "visual_enc_features": uniform((Tv, 32), 1.0, stream_id(9, f"v{i}")).float(),
+                    "audio_mask_targets": torch.tensor([i % 3, 0, 1, 2]), "visual_mask_targets": torch.tensor([2, (i + 1) % 3, 0, 1, 1])})
+    names = ["audio_noise_classifier.conv1.weight", "visual_noise_classifier.classifier.bias", "audio_noise_classifier.conv2.bias"]
+    m = fresh()
+    before = {k: v.detach().float().cpu().clone() for k, v in m.named_parameters() if k in names}
+    # the loss fit optimises = LM loss + 0.02 x mask loss (first micro-batch, evaluated here the same way)
+    seen = []
+    tc = TrainConfig(learning_rate=1e-3, classifier_learning_rate=5e-3, num_epochs=1, batch_size=4, micro_batch_size=1,
+                     lm_head_chunk_size=8, shuffle=False, warmup_frac=0.2)
+    out = fit(m, exs, collate, tc, device=DEV, log=lambda s: None, on_micro=lambda it, loss: seen.append(loss.float().item()))
+    assert out["optimizer_steps"] == 2
+    after = {k: v.detach().float().cpu() for k, v in m.named_parameters() if k in names}
+    assert all(p.dtype == torch.float32 and p.requires_grad for n, p in m.named_parameters() if "noise_classifier" in n)
+    assert all(not torch.equal(before[k], after[k]) for k in names), "every classifier parameter must move"
+    # classifier learning rate 0: the second group is really a separate group — LoRA moves, the classifiers do not
+    m0 = fresh()
+    lora0 = m0.transformer.h[0].attn.proj.lora_B.detach().float().cpu().clone()
+    tc0 = TrainConfig(learning_rate=1e-3, classifier_learning_rate=0.0, weight_decay=0.0, num_epochs=1, batch_size=4, micro_batch_size=1,
+                      lm_head_chunk_size=8, shuffle=False)
+    fit(m0, exs, collate, tc0, device=DEV, log=lambda s: None)
+    after0 = {k: v.detach().float().cpu() for k, v in m0.named_parameters() if k in names}
+    assert all(torch.equal(before[k], after0[k]) for k in names)
+    assert not torch.equal(lora0, m0.transformer.h[0].attn.proj.lora_B.detach().float().cpu())
+    # the first micro-batch's loss is LM + 0.02 x (audio + visual CE)
+    m1 = fresh()
+    from dualhyp_amd.train import prepare_for_training
+    from dualhyp_amd.relprompt import prepare_classifiers_for_training
+    m1.train(); prepare_for_training(m1); prepare_classifiers_for_training(m1)
+    b = collate(exs[:1])
+    lm = micro_loss(m1, b["input_ids"].to(DEV), b["labels"].to(DEV), 8)
+    ml = mask_loss(m1.audio_noise_classifier(b["audio_enc_features"].to(DEV)), m1.visual_noise_classifier(b["visual_enc_features"].to(DEV)),
+                   b["audio_mask_targets"].to(DEV), b["visual_mask_targets"].to(DEV))
+    assert ml.item() > 0.5 and abs(seen[0] - (lm.item() + 0.02 * ml.item())) <= 2e-3 * abs(seen[0]), (seen[0], lm.item(), ml.item())
