@@ -46,8 +46,9 @@ SIGNATURES = {
     "dh_linear_qkv_rope_cache_bf16": (I, [P, P, I, I, P, I, P, F, P, P, P, P, P, P, P, I, I, I, I, P]),
     "dh_linear_partial_bf16": (I, [P, P, P, P, I, I, I, I, I, P]),
     "dh_linear_chain_bf16": (I, [P, P, P, P, I, I, I, I, I, P]),
-    "dh_finish_norm_bf16": (I, [P, I, I, I, I, P, F, P, P, P, P, F, P, P]),
-    "dh_attn_decode_fused_bf16": (I, [P, I, I, I, I, P, F, I, I, P, P, P, P, P, P, P, I, I, I, I, P]),
+    "dh_linear_partial_pairs_bf16": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "dh_finish_norm_bf16": (I, [P, I, I, I, I, I, P, F, P, P, P, P, F, P, P]),
+    "dh_attn_decode_fused_bf16": (I, [P, I, I, I, I, I, P, F, I, I, P, P, P, P, P, P, P, I, I, I, I, P]),
     "dh_attn_prefill_bf16": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "dh_swiglu_fwd_bf16": (I, [P, P, P, I64, P]),
     "dh_swiglu_bwd_bf16": (I, [P, P, P, P, I, I, P]),

@@ -19,7 +19,7 @@ constexpr int MAXP = 16;    // most K-slices a partial-sum GEMM emits
 // columns [qkv_dim, qkv_dim+48) hold x·A^T of the q/k/v LoRA (when lora_b != null).
 template <int HS, int PMAX>
 __global__ __launch_bounds__(512, HS == 64 ? 4 : 2) void attn_decode_fused_kernel(
-    const float* __restrict__ qkv32, int n_part, int n_seq, int ldq, int qkv_dim,
+    const float* __restrict__ qkv32, int n_part, int pairs, int n_seq, int ldq, int qkv_dim,
     const bf16_t* __restrict__ lora_b, float lora_scale, int split0, int split1,
     const bf16_t* __restrict__ cos, const bf16_t* __restrict__ sin, const int32_t* __restrict__ seq_slot,
     const int32_t* __restrict__ kv_len, bf16_t* __restrict__ k_cache, bf16_t* __restrict__ vT_cache,
@@ -74,9 +74,16 @@ __global__ __launch_bounds__(512, HS == 64 ? 4 : 2) void attn_decode_fused_kerne
         float v[PMAX];
 #pragma unroll
         for (int p = 0; p < PMAX; ++p) v[p] = p < n_part ? row0[p * pstride + c] : 0.f;
+        // the decode family's summation order (common.h, "K-slice combine"): leaves are added in adjacent PAIRS, the
+        // pair sums in index order; a producer that owns two slices per block has already formed the pairs (pairs == 0)
         float s = 0.f;
+        if (pairs) {
 #pragma unroll
-        for (int p = 0; p < PMAX; ++p) s += v[p];
+            for (int p = 0; p < PMAX; p += 2) s += v[p] + v[p + 1];
+        } else {
+#pragma unroll
+            for (int p = 0; p < PMAX; ++p) s += v[p];
+        }
         return s;
     };
     if (lora_b != nullptr && tid < 48) sXa[tid] = rbf(psum(qkv_dim + tid));
@@ -254,7 +261,7 @@ constexpr size_t attn_fused_lds() {
 //   x' = bf16( x + h )                                           (residual, ger/model.py:185-186)
 //   xn = RMSNorm(x') with weight w_norm                          (ger/rmsnorm.py:17-21, Q11 flag)
 template <int MAXC>
-__global__ __launch_bounds__(256) void finish_norm_kernel(const float* __restrict__ h32, int n_part, int rows, int ldh,
+__global__ __launch_bounds__(256) void finish_norm_kernel(const float* __restrict__ h32, int n_part, int pairs, int rows, int ldh,
                                                           const bf16_t* __restrict__ lora_b, float lora_scale,
                                                           const bf16_t* __restrict__ x_resid,
                                                           const bf16_t* __restrict__ w_norm, bf16_t* __restrict__ x_out,
@@ -270,8 +277,13 @@ __global__ __launch_bounds__(256) void finish_norm_kernel(const float* __restric
 #pragma unroll
         for (int p = 0; p < MAXP; ++p) pv[p] = p < n_part ? hrow[p * pstride + d + tid] : 0.f;
         float s = 0.f;
+        if (pairs) {
 #pragma unroll
-        for (int p = 0; p < MAXP; ++p) s += pv[p];
+            for (int p = 0; p < MAXP; p += 2) s += pv[p] + pv[p + 1];
+        } else {
+#pragma unroll
+            for (int p = 0; p < MAXP; ++p) s += pv[p];
+        }
         sXa[tid] = rbf(s);
     }
     __syncthreads();
@@ -293,12 +305,24 @@ __global__ __launch_bounds__(256) void finish_norm_kernel(const float* __restric
                     a0[q] = *reinterpret_cast<const float4*>(hrow + p * pstride + c0);
                     a1[q] = *reinterpret_cast<const float4*>(hrow + p * pstride + c0 + 4);
                 }
+                if (pairs) {      // leaves: adjacent pairs first (a missing partner counts as 0), pair sums in order
+#pragma unroll
+                    for (int q = 0; q < 4; q += 2) {
+                        if (p0 + q < n_part) {
+                            const bool two = p0 + q + 1 < n_part;
+                            const float4 b0 = two ? a0[q + 1] : float4{0.f, 0.f, 0.f, 0.f}, b1 = two ? a1[q + 1] : float4{0.f, 0.f, 0.f, 0.f};
+                            acc[0] += a0[q].x + b0.x; acc[1] += a0[q].y + b0.y; acc[2] += a0[q].z + b0.z; acc[3] += a0[q].w + b0.w;
+                            acc[4] += a1[q].x + b1.x; acc[5] += a1[q].y + b1.y; acc[6] += a1[q].z + b1.z; acc[7] += a1[q].w + b1.w;
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if (p0 + q < n_part) {
                         acc[0] += a0[q].x; acc[1] += a0[q].y; acc[2] += a0[q].z; acc[3] += a0[q].w;
                         acc[4] += a1[q].x; acc[5] += a1[q].y; acc[6] += a1[q].z; acc[7] += a1[q].w;
                     }
+                }
                 }
             }
             const uint4 xr = *reinterpret_cast<const uint4*>(x_resid + (size_t)row * d + c0);
@@ -352,7 +376,7 @@ __global__ __launch_bounds__(256) void finish_norm_kernel(const float* __restric
 
 }  // namespace
 
-extern "C" int dh_attn_decode_fused_bf16(const float* qkv32, int n_part, int n_seq, int qkv_dim, int n_ext,
+extern "C" int dh_attn_decode_fused_bf16(const float* qkv32, int n_part, int pairs, int n_seq, int qkv_dim, int n_ext,
                                          const dh_bf16* lora_b, float lora_scale, int split0, int split1,
                                          const dh_bf16* cos, const dh_bf16* sin, const int32_t* seq_slot,
                                          const int32_t* kv_len, dh_bf16* k_cache, dh_bf16* vT_cache, dh_bf16* y,
@@ -368,7 +392,7 @@ extern "C" int dh_attn_decode_fused_bf16(const float* qkv32, int n_part, int n_s
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(n_seq * n_groups), block(512);
 #define ATT_LAUNCH(HSV, PM)                                                                                           \
-    hipLaunchKernelGGL((attn_decode_fused_kernel<HSV, PM>), grid, block, attn_fused_lds<HSV>(), s, qkv32, n_part, n_seq,  \
+    hipLaunchKernelGGL((attn_decode_fused_kernel<HSV, PM>), grid, block, attn_fused_lds<HSV>(), s, qkv32, n_part, pairs, n_seq,  \
                        qkv_dim + n_ext, qkv_dim, lora_b, lora_scale, split0, split1, cos, sin, seq_slot, kv_len, k_cache,  \
                        vT_cache, y, n_head, n_groups, s_max, scale)
     if (hs == 64) {
@@ -388,7 +412,7 @@ extern "C" int dh_attn_decode_fused_bf16(const float* qkv32, int n_part, int n_s
     return 0;
 }
 
-extern "C" int dh_finish_norm_bf16(const float* h32, int n_part, int rows, int d, int n_ext, const dh_bf16* lora_b,
+extern "C" int dh_finish_norm_bf16(const float* h32, int n_part, int pairs, int rows, int d, int n_ext, const dh_bf16* lora_b,
                                    float lora_scale, const dh_bf16* x_resid, const dh_bf16* w_norm, dh_bf16* x_out,
                                    dh_bf16* xn_out, float eps, const uint8_t* row_tail, void* stream) {
     DH_CHECK(h32 && x_resid && w_norm && x_out && xn_out, "dh_finish_norm_bf16: null argument");
@@ -399,7 +423,7 @@ extern "C" int dh_finish_norm_bf16(const float* h32, int n_part, int rows, int d
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(rows), block(256);
     const int ldh = d + n_ext;
-#define LAUNCH(MAXC) hipLaunchKernelGGL((finish_norm_kernel<MAXC>), grid, block, 0, s, h32, n_part, rows, ldh, lora_b, \
+#define LAUNCH(MAXC) hipLaunchKernelGGL((finish_norm_kernel<MAXC>), grid, block, 0, s, h32, n_part, pairs, rows, ldh, lora_b, \
                                         lora_scale, x_resid, w_norm, x_out, xn_out, d, eps, row_tail)
     if (d <= 2048) { LAUNCH(1); }
     else if (d <= 4096) { LAUNCH(2); }

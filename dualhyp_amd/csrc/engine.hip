@@ -243,7 +243,7 @@ int run_layers_fp8(dh_engine* e, const int64_t* ids, int n_tok, int n_seq, int m
                                             n_tok, e->qkv_dim, d, s))) return rc;
             }
             TimeScope t(e, 3, s);
-            if ((rc = dh_attn_decode_fused_bf16(e->part32, 1, n_seq, e->qkv_dim, 0, nullptr, 0.f, e->qkv_dim, e->qkv_dim,
+            if ((rc = dh_attn_decode_fused_bf16(e->part32, 1, 0, n_seq, e->qkv_dim, 0, nullptr, 0.f, e->qkv_dim, e->qkv_dim,
                                                 D.rope_cos, D.rope_sin, seq_slot, kv_pos0, kc, vtc, e->att, H, G, hs,
                                                 e->s_max, s))) return rc;
         } else {
@@ -320,35 +320,29 @@ int run_layers_decode(dh_engine* e, const int64_t* ids, int n_seq, const uint8_t
         const dh_layer_weights& W = e->layers[l];
         bf16_t* kc = e->kc + (size_t)l * e->cache_layer_elems;
         bf16_t* vtc = e->vtc + (size_t)l * e->cache_layer_elems;
+        // every partial-sum GEMM: the total in one launch (chain), the pair sums from the tiled split-K kernel (more than
+        // 128 rows), or the K-slices from the streaming kernel — all in the family's one combine order (dualhyp_hip.h)
+        auto partial = [&](const bf16_t* xin, const bf16_t* w, const bf16_t* wext, int N, int ext, int K, int ks, int& np, int& pairs) {
+            if (dh_chain_ok(n_seq, N, ext, K, ks)) { np = 1; pairs = 0; return dh_linear_chain_bf16(xin, w, wext, e->part32, n_seq, N, ext, K, ks, s); }
+            if (dh_pairs_ok(n_seq, N, ext, K, ks)) { np = (ks + 1) / 2; pairs = 0; return dh_linear_partial_pairs_bf16(xin, w, wext, e->part32, n_seq, N, ext, K, ks, s); }
+            np = ks; pairs = 1;
+            return dh_linear_partial_bf16(xin, w, wext, e->part32, n_seq, N, ext, K, ks, s);
+        };
+        int np, pairs;
         const int ext1 = W.attn_lora_a ? 48 : 0;
-        const int ks1 = pick_ksplit((e->qkv_dim + ext1) / 16, d / 32);
-        int np1 = ks1;   // partial sums the consumer adds up (1: the tiled kernel already did, in the same order)
-        if (dh_chain_ok(n_seq, e->qkv_dim, ext1, d, ks1)) {
-            np1 = 1;
-            if ((rc = dh_linear_chain_bf16(e->xn, W.attn_w, W.attn_lora_a, e->part32, n_seq, e->qkv_dim, ext1, d, ks1, s))) return rc;
-        } else if ((rc = dh_linear_partial_bf16(e->xn, W.attn_w, W.attn_lora_a, e->part32, n_seq, e->qkv_dim, ext1, d, ks1, s))) return rc;
-        if ((rc = dh_attn_decode_fused_bf16(e->part32, np1, n_seq, e->qkv_dim, ext1, W.attn_lora_b, D.lora_scale, d,
+        if ((rc = partial(e->xn, W.attn_w, W.attn_lora_a, e->qkv_dim, ext1, d, pick_ksplit((e->qkv_dim + ext1) / 16, d / 32), np, pairs))) return rc;
+        if ((rc = dh_attn_decode_fused_bf16(e->part32, np, pairs, n_seq, e->qkv_dim, ext1, W.attn_lora_b, D.lora_scale, d,
                                             d + e->kv_dim, D.rope_cos, D.rope_sin, seq_slot, kv_len, kc, vtc, e->att, H, G,
                                             hs, e->s_max, s))) return rc;
         const int ext2 = W.proj_lora_a ? 16 : 0;
-        const int ks2 = pick_ksplit((d + ext2) / 16, d / 32);
-        int np2 = ks2;
-        if (dh_chain_ok(n_seq, d, ext2, d, ks2)) {
-            np2 = 1;
-            if ((rc = dh_linear_chain_bf16(e->att, W.proj_w, W.proj_lora_a, e->part32, n_seq, d, ext2, d, ks2, s))) return rc;
-        } else if ((rc = dh_linear_partial_bf16(e->att, W.proj_w, W.proj_lora_a, e->part32, n_seq, d, ext2, d, ks2, s))) return rc;
-        if ((rc = dh_finish_norm_bf16(e->part32, np2, n_seq, d, ext2, W.proj_lora_b, D.lora_scale, e->x, W.norm_2, e->x,
+        if ((rc = partial(e->att, W.proj_w, W.proj_lora_a, d, ext2, d, pick_ksplit((d + ext2) / 16, d / 32), np, pairs))) return rc;
+        if ((rc = dh_finish_norm_bf16(e->part32, np, pairs, n_seq, d, ext2, W.proj_lora_b, D.lora_scale, e->x, W.norm_2, e->x,
                                       e->xn, D.norm_eps, rt, s))) return rc;
         if ((rc = linear(e, e->xn, W.fc_1, e->act, n_seq, I, d, DH_EPI_SWIGLU, W.fc_2, nullptr, 0, nullptr, 0, 0, nullptr,
                          nullptr, nullptr, s, false))) return rc;
-        const int ks3 = pick_ksplit(d / 16, I / 32);
-        int np3 = ks3;
-        if (dh_chain_ok(n_seq, d, 0, I, ks3)) {
-            np3 = 1;
-            if ((rc = dh_linear_chain_bf16(e->act, W.mlp_proj, nullptr, e->part32, n_seq, d, 0, I, ks3, s))) return rc;
-        } else if ((rc = dh_linear_partial_bf16(e->act, W.mlp_proj, nullptr, e->part32, n_seq, d, 0, I, ks3, s))) return rc;
+        if ((rc = partial(e->act, W.mlp_proj, nullptr, d, 0, I, pick_ksplit(d / 16, I / 32), np, pairs))) return rc;
         const bf16_t* next_norm = l + 1 < D.n_layer ? e->layers[l + 1].norm_1 : D.ln_f;
-        if ((rc = dh_finish_norm_bf16(e->part32, np3, n_seq, d, 0, nullptr, 0.f, e->x, next_norm, e->x, e->xn,
+        if ((rc = dh_finish_norm_bf16(e->part32, np, pairs, n_seq, d, 0, nullptr, 0.f, e->x, next_norm, e->x, e->xn,
                                       D.norm_eps, rt, s))) return rc;
     }
     return 0;

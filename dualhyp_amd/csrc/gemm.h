@@ -45,6 +45,11 @@ extern int g_mid;            // 1: the decode phase uses the LDS-staged-x stream
 bool dh_linear_dt_ok(const GemmArgs& a, int epilogue, int seg);
 int dh_linear_dt(const GemmArgs& a, int epilogue, int seg, hipStream_t s);
 bool dh_chain_ok(int M, int n_main, int n_ext, int K, int ksplit);
+// decode partial-sum GEMM of M rows: true = the tiled split-K kernel (pair sums, (ksplit+1)/2 partials), false = the
+// K-sliced streaming kernel (ksplit slices); the consumers' `pairs` flag is the negation
+bool dh_pairs_ok(int M, int n_main, int n_ext, int K, int ksplit);
+int dh_pairs_tiled(const bf16_t* x, const bf16_t* w, const bf16_t* w_ext, float* y32, int M, int n_main, int n_ext, int K,
+                   int kps, hipStream_t s);
 int dh_chain_tiled(const bf16_t* x, const bf16_t* w, const bf16_t* w_ext, float* y32, int M, int n_main, int n_ext, int K,
                    int kps, hipStream_t s);
 extern int g_dt_min_rows, g_chain_min_rows;

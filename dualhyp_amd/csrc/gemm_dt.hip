@@ -14,9 +14,13 @@
 // added in its LDS reduction).  This kernel runs the same chains — same MFMA instruction and operand
 // roles, `cur` restarted at every segment boundary and folded into `tot` in order — so a row's result is
 // the same whichever kernel computed it (tests: test_linear_partial_wide_rows, test_joint_decode_*).
-//   MODE 0 : fp32 output [M][N] of x·[w; w_ext]^T (the sum of the rows kernel's partials)
+//   MODE 0 : fp32 output [M][N] of x·[w; w_ext]^T (the rows kernel's partials combined in the family's order: adjacent
+//            slices added in PAIRS, the pair sums in index order — three accumulator sets)
+//   MODE 4 : split-K over blocks, fp32 output [ceil(slices/2)][M][N]: block (tile, y) walks the TWO K-slices 2y, 2y+1 and
+//            stores their sum — the pair sums of that same order, half the partial-sum bytes of the rows kernel and whole
+//            tiles per block (round 3: the decode GEMMs above 128 rows)
 //   MODE 1 : SwiGLU pair, bf16 output; MODE 2 : adapter scale/bias; MODE 3 : plain (+ residual)
-//   grid   : m-tiles fastest, then n-tiles
+//   grid   : m-tiles fastest, then n-tiles (x K-slice pairs in MODE 4)
 #include "common.h"
 #include "gemm.h"
 
@@ -40,6 +44,7 @@ struct DtArgs {
     const bf16_t* vec_b;
     const bf16_t* resid;
     int M, N, K, n_main, seg;   // seg: k-steps per chain segment (even)
+    int split_kt;               // MODE 4: 64-wide stages per block (two segments); else 0
 };
 
 // NSTAGE 4: one block per CU, 3 stages in flight; NSTAGE 2: two blocks per CU.  WN 2: 4 waves, 128 W rows per block;
@@ -60,10 +65,11 @@ __global__ __launch_bounds__(WN * 128) void gemm_dt_kernel(DtArgs a) {
     // XCD-aware order (blocks go round-robin over the 8 XCDs, each with its own L2): an XCD walks a CONTIGUOUS range of
     // the m-fastest tile order, so the m-tiles that share a W tile meet in one L2 instead of fetching it over the fabric
     // once per XCD (at 640 rows that was 5 x 46 MB per SwiGLU launch = 5.2 TB/s: the limit of the kernel).
-    int tile;
+    int tile, ky = 0;       // ky: MODE 4's K-slice pair (grid.y); the XCD walk runs over the whole 2-D grid, tiles fastest
     {
-        const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int nwg = gridDim.x * gridDim.y, bid = blockIdx.x + gridDim.x * blockIdx.y, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        if (MODE == 4) { ky = tile / (int)gridDim.x; tile -= ky * (int)gridDim.x; }
     }
     const int tm = tile % m_tiles, tn = tile / m_tiles;
     const int m0 = tm * TB;
@@ -88,9 +94,9 @@ __global__ __launch_bounds__(WN * 128) void gemm_dt_kernel(DtArgs a) {
         } else {
             n = n0 + row;
             n = n < a.N ? n : a.N - 1;
-            if (MODE == 0 && n >= a.n_main) { base = a.w2; n -= a.n_main; }
+            if ((MODE == 0 || MODE == 4) && n >= a.n_main) { base = a.w2; n -= a.n_main; }
         }
-        srcA[j] = base + (size_t)n * a.K + chunk * 8;
+        srcA[j] = base + (size_t)n * a.K + chunk * 8 + (MODE == 4 ? (size_t)ky * a.split_kt * BKD : 0);
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -99,7 +105,7 @@ __global__ __launch_bounds__(WN * 128) void gemm_dt_kernel(DtArgs a) {
         const int chunk = (lane & 7) ^ swz7(row);
         int m = m0 + row;
         m = m < a.M ? m : a.M - 1;
-        srcB[j] = a.x + (size_t)m * a.K + chunk * 8;
+        srcB[j] = a.x + (size_t)m * a.K + chunk * 8 + (MODE == 4 ? (size_t)ky * a.split_kt * BKD : 0);
     }
     auto stage = [&](int kt) __attribute__((always_inline)) {
         char* sA = smem + (kt % NSTAGE) * STAGE;
@@ -126,8 +132,10 @@ __global__ __launch_bounds__(WN * 128) void gemm_dt_kernel(DtArgs a) {
         }
     const int sw = swz7(frow);
     const int offA = (wn * 64 + frow) * 128, offB = (wm * 64 + frow) * 128;
-    const int nk = a.K / BKD;
+    const int nk = MODE == 4 ? min(a.split_kt, a.K / BKD - ky * a.split_kt) : a.K / BKD;
     const int seg_kt = a.seg / 2;       // stages per chain segment
+    f32x4 pairacc[MODE == 0 ? 4 : 1][MODE == 0 ? 4 : 1];   // MODE 0: the open pair's first slice
+    int seg_idx = 0;
 
     // prologue: NSTAGE-1 stages requested, the first one waited for
 #pragma unroll
@@ -158,6 +166,21 @@ __global__ __launch_bounds__(WN * 128) void gemm_dt_kernel(DtArgs a) {
         }
         if (++in_seg == seg_kt || kt + 1 == nk) {     // end of a chain segment: fold it in, in order
             in_seg = 0;
+            if (MODE == 0) {
+                // the partial-sum family's order: (s0 + s1) + (s2 + s3) + ... — slices in adjacent pairs, pair sums in
+                // index order; an unpaired last slice is added on its own
+                const bool second = seg_idx & 1, last = kt + 1 == nk;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (second) tot[i][j] += pairacc[i][j] + cur[i][j];
+                        else if (last) tot[i][j] += cur[i][j];
+                        else pairacc[i][j] = cur[i][j];
+                        cur[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                ++seg_idx;
+            } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -165,6 +188,7 @@ __global__ __launch_bounds__(WN * 128) void gemm_dt_kernel(DtArgs a) {
                     tot[i][j] += cur[i][j];
                     cur[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
+            }
         }
         // own share of stage kt+1 landed (later stages may stay in flight), then everybody's
         {
@@ -198,8 +222,9 @@ __global__ __launch_bounds__(WN * 128) void gemm_dt_kernel(DtArgs a) {
             for (int i = 0; i < 4; ++i) {
                 const int n = n0 + wn * 64 + i * 16 + kg * 4;
                 if (n >= a.N) continue;
-                if (MODE == 0) {
-                    *reinterpret_cast<f32x4*>((float*)a.y + (size_t)m * a.N + n) = tot[i][j];
+                if (MODE == 0 || MODE == 4) {
+                    float* yo = (float*)a.y + (MODE == 4 ? (size_t)ky * a.M * a.N : 0);
+                    *reinterpret_cast<f32x4*>(yo + (size_t)m * a.N + n) = tot[i][j];
                     continue;
                 }
                 float o[4];
@@ -221,10 +246,10 @@ __global__ __launch_bounds__(WN * 128) void gemm_dt_kernel(DtArgs a) {
 }
 
 template <int MODE, int NSTAGE, int WN = 2>
-int launch_dt_n(const DtArgs& a, int blocks, hipStream_t s) {
+int launch_dt_n(const DtArgs& a, int blocks, hipStream_t s, int ny = 1) {
     constexpr int lds = NSTAGE * stage_bytes<WN>();     // WN 2: 128 KiB / 64 KiB; WN 4: 144 KiB
     DH_MAX_LDS_ONCE((gemm_dt_kernel<MODE, NSTAGE, WN>), lds);
-    hipLaunchKernelGGL((gemm_dt_kernel<MODE, NSTAGE, WN>), dim3(blocks), dim3(WN * 128), lds, s, a);
+    hipLaunchKernelGGL((gemm_dt_kernel<MODE, NSTAGE, WN>), dim3(blocks, ny), dim3(WN * 128), lds, s, a);
     DH_LAUNCH_CHECK();
     return 0;
 }
@@ -260,8 +285,24 @@ int g_chain_min_rows = 1280;   // partial-sum GEMMs from this many rows on (dh_s
 // x·[w; w_ext]^T summed over the K-slices of `kps` k-steps in slice order: fp32 [M][n_main + n_ext]
 int dh_chain_tiled(const bf16_t* x, const bf16_t* w, const bf16_t* w_ext, float* y32, int M, int n_main, int n_ext, int K,
                    int kps, hipStream_t s) {
-    DtArgs a{x, w, w_ext ? w_ext : w, y32, nullptr, nullptr, nullptr, M, n_main + n_ext, K, n_main, kps};
+    DtArgs a{x, w, w_ext ? w_ext : w, y32, nullptr, nullptr, nullptr, M, n_main + n_ext, K, n_main, kps, 0};
     return launch_dt<0>(a, s);
+}
+
+// The pair sums of the K-slices (kps k-steps each) of x·[w; w_ext]^T: fp32 [ceil(nslices / 2)][M][n_main + n_ext], one
+// block per (tile, slice pair).  Tile shape by grid size: 128 x 256 on 8 waves (3 stages of 48 KiB) when that still gives
+// every CU a block, else 128 x 128 on 4 waves (dh_set_tuning key 17: 0 auto, 2 / 4 = waves along n).
+int g_pairs_wn = 0;
+int dh_pairs_tiled(const bf16_t* x, const bf16_t* w, const bf16_t* w_ext, float* y32, int M, int n_main, int n_ext, int K,
+                   int kps, hipStream_t s) {
+    const int N = n_main + n_ext, nslices = cdiv(K / 32, kps), ny = (nslices + 1) / 2;
+    DtArgs a{x, w, w_ext ? w_ext : w, y32, nullptr, nullptr, nullptr, M, N, K, n_main, kps, kps};   // kps k-steps = kps/2 stages per slice, two slices per block
+    const int m_tiles = cdiv(M, TB);
+    const int wide_blocks = m_tiles * cdiv(N, 256) * ny;
+    const bool wide = g_pairs_wn ? g_pairs_wn == 4 : wide_blocks >= 200;
+    if (wide) return launch_dt_n<4, 3, 4>(a, m_tiles * cdiv(N, 256), s, ny);
+    const int blocks = m_tiles * cdiv(N, TB);
+    return blocks * ny > 256 ? launch_dt_n<4, 2>(a, blocks, s, ny) : launch_dt_n<4, 4>(a, blocks, s, ny);
 }
 
 bool dh_linear_dt_ok(const GemmArgs& a, int epilogue, int seg) {
@@ -270,7 +311,7 @@ bool dh_linear_dt_ok(const GemmArgs& a, int epilogue, int seg) {
 }
 
 int dh_linear_dt(const GemmArgs& g, int epilogue, int seg, hipStream_t s) {
-    DtArgs a{g.x, g.w, g.w2, g.y, g.vec_a, g.vec_b, g.resid, g.M, g.N, g.K, g.N, seg};
+    DtArgs a{g.x, g.w, g.w2, g.y, g.vec_a, g.vec_b, g.resid, g.M, g.N, g.K, g.N, seg, 0};
     switch (epilogue) {
         case DH_EPI_SWIGLU: return launch_dt<1>(a, s);
         case DH_EPI_ADAPTER: return launch_dt<2>(a, s);

@@ -511,6 +511,23 @@ bool dh_chain_ok(int M, int n_main, int n_ext, int K, int ksplit) {
            N % 4 == 0 && n_main % ROWS == 0 && n_ext % ROWS == 0;
 }
 
+int g_pairs_min_rows = 129;   // partial-sum GEMMs of at least this many rows take the tiled split-K kernel (dh_set_tuning key 18)
+bool dh_pairs_ok(int M, int n_main, int n_ext, int K, int ksplit) {
+    const int nks = K / 32, kps = (nks + ksplit - 1) / ksplit, N = n_main + n_ext;
+    return g_skinny_variant == 1 && M >= g_pairs_min_rows && K % 64 == 0 && (kps == 8 || kps == 16) && ksplit * kps == nks &&
+           N % 4 == 0 && n_main % ROWS == 0 && n_ext % ROWS == 0;
+}
+
+extern "C" int dh_linear_partial_pairs_bf16(const dh_bf16* x, const dh_bf16* w, const dh_bf16* w_ext, float* y32, int M,
+                                            int n_main, int n_ext, int K, int ksplit, void* stream) {
+    DH_CHECK(x && w && y32 && M >= 1 && ksplit >= 1 && ksplit <= 16 && (n_ext == 0 || w_ext), "dh_linear_partial_pairs_bf16: bad argument");
+    const int nks = K / 32, kps = (nks + ksplit - 1) / ksplit;
+    DH_CHECK(K % 64 == 0 && (kps == 8 || kps == 16) && ksplit * kps == nks && (n_main + n_ext) % 4 == 0 && n_main % ROWS == 0 &&
+             n_ext % ROWS == 0, "dh_linear_partial_pairs_bf16: unsupported shape N=%d+%d K=%d ksplit=%d (K %% 64 == 0, whole K-slices of 8 or 16 k-steps)",
+             n_main, n_ext, K, ksplit);
+    return dh_pairs_tiled(x, w, w_ext, y32, M, n_main, n_ext, K, kps, (hipStream_t)stream);
+}
+
 extern "C" int dh_linear_chain_bf16(const dh_bf16* x, const dh_bf16* w, const dh_bf16* w_ext, float* y32, int M, int n_main,
                                     int n_ext, int K, int ksplit, void* stream) {
     DH_CHECK(x && w && y32 && M >= 1 && ksplit >= 1 && (n_ext == 0 || w_ext), "dh_linear_chain_bf16: bad argument");
@@ -539,6 +556,8 @@ extern "C" int dh_set_tuning(int key, int value) {
     if (key == 16 && (value == 8 || value == 16)) { extern int g_short_kps; g_short_kps = value; return 0; }
     if (key == 15) { extern int g_dt_wide; g_dt_wide = value; return 0; }
     if (key == 13) { extern int g_mid_wlds; g_mid_wlds = value; return 0; }
+    if (key == 17 && (value == 0 || value == 2 || value == 4)) { extern int g_pairs_wn; g_pairs_wn = value; return 0; }
+    if (key == 18 && value >= 1) { g_pairs_min_rows = value; return 0; }
     dh_set_error("dh_set_tuning: unknown key %d", key);
     return 1;
 }

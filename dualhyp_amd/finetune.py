@@ -112,6 +112,10 @@ class TrainConfig:
     # their own AdamW group with their own learning rate, on the mask cross entropy weighted by mask_loss_weight
     classifier_learning_rate: float = 1e-4
     mask_loss_weight: float = 0.02
+    # up to `pack` micro-batches of one accumulation window run as ONE packed forward / backward replayed from a
+    # hipGraph (train.GraphedTrainStep): same per-sequence losses and the sum of their gradients, but the GEMMs see
+    # pack x T rows.  1 = every micro-batch on its own through torch autograd (the reference's schedule, launch by launch)
+    pack: int = 1
 
 
 def micro_loss(model, input_ids: torch.Tensor, labels: torch.Tensor, chunk: int) -> torch.Tensor:
@@ -170,26 +174,53 @@ def fit(model, train_examples: Sequence[Dict[str, torch.Tensor]], collate: Calla
     max_iters = cfg.num_epochs * epoch_size // world
     it, micro, steps, best_val, last = 0, 0, 0, float("inf"), float("nan")
     loss_acc = torch.zeros((), device=device)          # no per-micro-step .item(): one host sync per log line
+    packed = None
+    if cfg.pack > 1:
+        assert cfg.micro_batch_size == 1 and not cls_params, "TrainConfig.pack: micro_batch_size 1, decoder-only fine-tune"
+        from .train import GraphedTrainStep
+        packed = GraphedTrainStep(model, bucket)
+    pending: List[tuple] = []                           # (iteration, example) of micro-batches not yet run (pack > 1)
+
+    def flush() -> None:
+        """run the pending micro-batches as one packed step; per-micro-batch bookkeeping as if they had run in turn"""
+        nonlocal loss_acc
+        if not pending:
+            return
+        exs = [ex for _, ex in pending]
+        batch = collate(exs)
+        losses = packed(batch["input_ids"].to(device), batch["labels"].to(device), 1.0 / accum,
+                        lengths=[int(ex["input_ids"].numel()) for ex in exs])
+        loss_acc += losses.sum()
+        if on_micro is not None:
+            for k, (it_k, _) in enumerate(pending):
+                on_micro(it_k, losses[k])
+        pending.clear()
+
     for epoch in range(cfg.num_epochs):
         order = epoch_order(len(train_examples), epoch, rank, world, shuffle=cfg.shuffle)
         for b0 in range(0, len(order) - cfg.micro_batch_size + 1, cfg.micro_batch_size):
-            batch = collate([train_examples[i] for i in order[b0:b0 + cfg.micro_batch_size]])
-            ids, labels = batch["input_ids"].to(device), batch["labels"].to(device)
             for g, base in zip(opt.param_groups, base_lrs):       # both groups follow the same schedule (relprompt.py:321-341)
                 g["lr"] = lr_at(it, base, warmup, max_iters, cfg.use_cosine_scheduler, cfg.min_lr_ratio)
-            loss = micro_loss(model, ids, labels, cfg.lm_head_chunk_size)
-            if cls_params and "audio_enc_features" in batch and "audio_mask_targets" in batch:
-                from .relprompt import mask_loss                   # finetune/relprompt.py:356-403
-                a_lg = model.audio_noise_classifier(batch["audio_enc_features"].to(device))
-                v_lg = model.visual_noise_classifier(batch["visual_enc_features"].to(device))
-                loss = loss + cfg.mask_loss_weight * mask_loss(a_lg, v_lg, batch["audio_mask_targets"].to(device),
-                                                               batch["visual_mask_targets"].to(device))
-            (loss / accum).backward()
-            loss_acc += loss.detach()
-            if on_micro is not None:
-                on_micro(it, loss.detach())
+            if packed is not None:
+                pending.append((it, train_examples[order[b0]]))
+            else:
+                batch = collate([train_examples[i] for i in order[b0:b0 + cfg.micro_batch_size]])
+                ids, labels = batch["input_ids"].to(device), batch["labels"].to(device)
+                loss = micro_loss(model, ids, labels, cfg.lm_head_chunk_size)
+                if cls_params and "audio_enc_features" in batch and "audio_mask_targets" in batch:
+                    from .relprompt import mask_loss                   # finetune/relprompt.py:356-403
+                    a_lg = model.audio_noise_classifier(batch["audio_enc_features"].to(device))
+                    v_lg = model.visual_noise_classifier(batch["visual_enc_features"].to(device))
+                    loss = loss + cfg.mask_loss_weight * mask_loss(a_lg, v_lg, batch["audio_mask_targets"].to(device),
+                                                                   batch["visual_mask_targets"].to(device))
+                (loss / accum).backward()
+                loss_acc += loss.detach()
+                if on_micro is not None:
+                    on_micro(it, loss.detach())
             micro += 1
             hit = (micro + 1) % accum == 0 if cfg.reference_accumulation else micro % accum == 0
+            if len(pending) >= cfg.pack or hit or (cfg.save_interval and (it + 1) % cfg.save_interval == 0):
+                flush()
             if hit:
                 bucket.all_reduce_mean()
                 opt.step()
@@ -209,6 +240,7 @@ def fit(model, train_examples: Sequence[Dict[str, torch.Tensor]], collate: Calla
                         best_val = v
                         if out_dir and rank == 0:
                             save_checkpoint(model, Path(out_dir) / "best_model.pth")
+    flush()     # micro-batches after the last optimizer step of the run (their gradients are dropped, as in the reference's loop)
     if val_batches is not None:
         v = validate(model, val_batches())
         if v < best_val:
@@ -266,6 +298,9 @@ def main(argv: Optional[Sequence[str]] = None) -> Dict[str, float]:
     p.add_argument("--out_dir", type=str, default=None, help="default ./runs/<exp_name>")
     p.add_argument("--reference_accumulation", action="store_true", help="quirk Q3: step every batch_size-1 micro-batches")
     p.add_argument("--seed", type=int, default=1337)
+    p.add_argument("--pack", type=int, default=8,
+                   help="micro-batches of one accumulation window run as one packed, hipGraph-replayed step (same losses, summed "
+                        "gradients; 1 = the reference's launch-by-launch schedule)")
     # finetune/relprompt.py:625,641-643 (RelPrompt: the reliability classifiers train in a second AdamW group)
     p.add_argument("--classifier_lr", type=float, default=1e-4)
     p.add_argument("--mask_loss_weight", type=float, default=0.02)
@@ -344,7 +379,8 @@ def main(argv: Optional[Sequence[str]] = None) -> Dict[str, float]:
                      micro_batch_size=args.micro_batch_size, warmup_frac=args.wp, use_cosine_scheduler=args.use_cosine_scheduler,
                      min_lr_ratio=args.min_lr_ratio, save_interval=max(args.save_interval // world, 1),
                      reference_accumulation=args.reference_accumulation, classifier_learning_rate=args.classifier_lr,
-                     mask_loss_weight=args.mask_loss_weight)
+                     mask_loss_weight=args.mask_loss_weight,
+                     pack=1 if (rel or args.micro_batch_size != 1) else max(args.pack, 1))
     log = logging.info if rank == 0 else (lambda s: None)
     t0 = time.perf_counter()
     out = fit(model, train, collate, tc, val_batches=val_batches, out_dir=str(out_dir), rank=rank, world=world, device=dev, log=log)

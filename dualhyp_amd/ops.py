@@ -299,8 +299,33 @@ def linear_partial(x: torch.Tensor, w: torch.Tensor, w_ext: Optional[torch.Tenso
     return y
 
 
+def linear_partial_pairs(x: torch.Tensor, w: torch.Tensor, w_ext: Optional[torch.Tensor] = None, ksplit: int = 1) -> torch.Tensor:
+    """fp32 [(ksplit+1)//2, M, n_main+n_ext]: sums of adjacent pairs of `linear_partial`'s slices, from the tiled split-K
+    kernel; dh_linear_partial_pairs_bf16."""
+    x, w = _dev(x, name="x"), _dev(w, name="w")
+    K = x.size(-1)
+    M = x.numel() // K
+    n_ext = 0 if w_ext is None else _dev(w_ext, name="w_ext").size(0)
+    y = torch.empty(((ksplit + 1) // 2, M, w.size(0) + n_ext), dtype=torch.float32, device=x.device)
+    check(_lib.load().dh_linear_partial_pairs_bf16(_p(x), _p(w), _p(w_ext), _p(y), M, w.size(0), n_ext, K, ksplit, _stream()))
+    return y
+
+
+def combine_partials(parts: torch.Tensor, pairs: bool = True) -> torch.Tensor:
+    """The decode family's K-slice combine order on the fp32 partials [n, M, N] (include/dualhyp_hip.h): adjacent slices in
+    pairs, pair sums in index order (`pairs=False`: the inputs already are pair sums).  torch fp32 adds: test helper."""
+    if pairs:
+        n = parts.size(0)
+        parts = torch.stack([parts[i] + parts[i + 1] if i + 1 < n else parts[i] for i in range(0, n, 2)])
+    out = parts[0].clone()
+    for p in parts[1:]:
+        out = out + p
+    return out
+
+
 def linear_chain(x: torch.Tensor, w: torch.Tensor, w_ext: Optional[torch.Tensor] = None, ksplit: int = 1) -> torch.Tensor:
-    """fp32 [M, n_main+n_ext]: the ksplit partials of `linear_partial` added in slice order (M >= 65); dh_linear_chain_bf16."""
+    """fp32 [M, n_main+n_ext]: the ksplit slices of `linear_partial` combined in the family's order (`combine_partials`)
+    by one launch of the tiled kernel (M >= 65); dh_linear_chain_bf16."""
     x, w = _dev(x, name="x"), _dev(w, name="w")
     K = x.size(-1)
     M = x.numel() // K
@@ -312,27 +337,29 @@ def linear_chain(x: torch.Tensor, w: torch.Tensor, w_ext: Optional[torch.Tensor]
 
 def finish_norm(h32: torch.Tensor, d: int, x_resid: torch.Tensor, w_norm: torch.Tensor, eps: float,
                 lora_b: Optional[torch.Tensor] = None, lora_scale: float = 1.0,
-                row_tail: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """(x_out, xn_out) = LoRA finish + residual + RMSNorm of fp32 partials; dh_finish_norm_bf16."""
+                row_tail: Optional[torch.Tensor] = None, pairs: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(x_out, xn_out) = LoRA finish + residual + RMSNorm of fp32 partials (`pairs`: they are K-slices, to be added in
+    adjacent pairs first; False: pair sums / the total); dh_finish_norm_bf16."""
     k = _Keep()
     n_part, rows, ld = h32.shape
     x_resid = _dev(x_resid, name="x_resid")
     x_out, xn_out = torch.empty_like(x_resid), torch.empty_like(x_resid)
-    check(_lib.load().dh_finish_norm_bf16(_p(h32), n_part, rows, d, ld - d, _p(lora_b), float(lora_scale), _p(x_resid),
+    check(_lib.load().dh_finish_norm_bf16(_p(h32), n_part, int(pairs), rows, d, ld - d, _p(lora_b), float(lora_scale), _p(x_resid),
                                           k(w_norm), _p(x_out), _p(xn_out), float(eps), _p(row_tail), _stream()))
     return x_out, xn_out
 
 
 def attn_decode_fused(qkv32: torch.Tensor, qkv_dim: int, lora_b: Optional[torch.Tensor], lora_scale: float,
                       splits: Tuple[int, int], cos: torch.Tensor, sin: torch.Tensor, seq_slot: torch.Tensor,
-                      kv_len: torch.Tensor, k_cache: torch.Tensor, vT_cache: torch.Tensor, n_head: int) -> torch.Tensor:
-    """Decode-step attention sub-layer from fp32 qkv partials; dh_attn_decode_fused_bf16."""
+                      kv_len: torch.Tensor, k_cache: torch.Tensor, vT_cache: torch.Tensor, n_head: int,
+                      pairs: bool = True) -> torch.Tensor:
+    """Decode-step attention sub-layer from fp32 qkv partials (`pairs` as in finish_norm); dh_attn_decode_fused_bf16."""
     k = _Keep()
     n_part, n_seq, ld = qkv32.shape
     n_groups, s_max, hs = k_cache.size(1), k_cache.size(2), k_cache.size(3)
     y = torch.empty((n_seq, n_head * hs), dtype=torch.bfloat16, device=qkv32.device)
     i32 = torch.int32
-    check(_lib.load().dh_attn_decode_fused_bf16(_p(qkv32), n_part, n_seq, qkv_dim, ld - qkv_dim, _p(lora_b),
+    check(_lib.load().dh_attn_decode_fused_bf16(_p(qkv32), n_part, int(pairs), n_seq, qkv_dim, ld - qkv_dim, _p(lora_b),
                                                 float(lora_scale), splits[0], splits[1], k(cos), k(sin),
                                                 k(seq_slot, i32), k(kv_len, i32), _p(k_cache), _p(vT_cache),
                                                 _p(y), n_head, n_groups, hs, s_max, _stream()))

@@ -283,18 +283,27 @@ class _Ctx:
 
 
 class GraphedTrainStep:
-    """One LoRA micro-step (micro-batch 1, as finetune/ger.py runs it) — forward, the reference's chunked
-    cross entropy (mean over ALL T-1 positions, Q5), backward, accumulation into the flat gradient bucket —
-    captured ONCE per padded length as a hipGraph and replayed.  The eager autograd path issues ~1500 launches
-    from Python per micro-step and is host-bound (48 ms at T = 560); the replay is one launch.
-    The sequence is right-padded to a multiple of `pad_to` with ignored positions: causal attention and the
-    row-wise kernels make real positions independent of the padding, ignored rows get zero gradient, and the
-    loss keeps the reference's denominator (T-1)."""
+    """LoRA micro-steps (micro-batch 1, as finetune/ger.py runs them) — forward, the reference's chunked cross entropy
+    (mean over ALL T-1 positions, Q5), backward, accumulation into the flat gradient bucket — captured ONCE per
+    (sequences, padded length) as a hipGraph and replayed.  The eager autograd path issues ~1500 launches from Python
+    per micro-step and is host-bound (48 ms at T = 560); the replay is one launch.
+
+    PACKING: a call may carry P sequences = P micro-batches of the same accumulation window.  They run as ONE packed
+    forward / backward (var-len causal attention keeps the sequences apart, every other kernel is row-wise), so the
+    GEMMs see M = P x T rows and take the 256-tile kernels instead of walking K with 6-27 blocks on 256 CUs
+    (M = 560: 0.04 of the MFMA peak).  `micro_batch_size 1` semantics are kept: each sequence's loss is its own mean
+    over its own T_i - 1 positions (Q5), each is scaled by the same `loss_scale` (1 / accumulation), and — every op
+    after the loss being linear in the per-row gradient — what is added to the bucket is the SUM of the P sequential
+    micro-steps' gradients, up to the fp32 summation order of the token contraction.
+
+    Sequences are right-padded to a common multiple of `pad_to` with ignored positions: causal attention and the
+    row-wise kernels make real positions independent of the padding, ignored rows get zero gradient."""
 
     def __init__(self, model: GPT, bucket, pad_to: int = 64) -> None:
         self.model, self.bucket, self.pad_to = model, bucket, pad_to
         self.params = lora_parameters(model)
-        assert [id(p) for p in self.params] == [id(p) for p in bucket.params], "bucket must hold lora_parameters(model) in order"
+        n = len(self.params)
+        assert [id(p) for p in self.params] == [id(p) for p in bucket.params[:n]], "bucket must start with lora_parameters(model) in order"
         self._graphs = {}
 
     def _body(self, st) -> None:
@@ -307,7 +316,7 @@ class GraphedTrainStep:
             model._row_tail_override = None
         lg = logits.view(-1, V)
         per, lse = ops.cross_entropy_fwd(lg, st["targets"])
-        st["loss"].copy_((per.sum() * st["inv_count"]).reshape(1))
+        st["loss"].copy_(per.view(st["ids"].size(0), -1).sum(1) * st["inv_count"])
         dlogits = ops.cross_entropy_bwd(lg, st["targets"], lse, st["grow"])
         grads = _DecoderFn.backward(ctx, dlogits.view(logits.shape))[2:]
         off = 0
@@ -315,38 +324,52 @@ class GraphedTrainStep:
             self.bucket.flat[off:off + p.numel()].add_(g.reshape(-1).to(torch.float32))
             off += p.numel()
 
-    def _state(self, T_pad: int, dev):
-        st = dict(ids=torch.zeros((1, T_pad), dtype=torch.int64, device=dev),
-                  targets=torch.full((T_pad,), -1, dtype=torch.int64, device=dev),
-                  grow=torch.zeros(T_pad, dtype=torch.float32, device=dev),
-                  tail=torch.zeros(T_pad, dtype=torch.uint8, device=dev),
-                  inv_count=torch.zeros(1, dtype=torch.float32, device=dev),
-                  loss=torch.zeros(1, dtype=torch.float32, device=dev))
+    def _state(self, P: int, T_pad: int, dev):
+        n = P * T_pad
+        st = dict(ids=torch.zeros((P, T_pad), dtype=torch.int64, device=dev),
+                  targets=torch.full((n,), -1, dtype=torch.int64, device=dev),
+                  grow=torch.zeros(n, dtype=torch.float32, device=dev),
+                  tail=torch.zeros(n, dtype=torch.uint8, device=dev),
+                  inv_count=torch.zeros(P, dtype=torch.float32, device=dev),
+                  loss=torch.zeros(P, dtype=torch.float32, device=dev))
         return st
 
     @torch.no_grad()
-    def __call__(self, input_ids: torch.Tensor, labels: torch.Tensor, loss_scale: float = 1.0) -> torch.Tensor:
-        """-> the micro-step's loss (device tensor [1], finetune/ger.py:278-281); d(loss_scale * loss) is ADDED to the bucket."""
-        assert input_ids.dim() == 2 and input_ids.size(0) == 1, "GraphedTrainStep: micro-batch 1 (the reference's setting)"
-        T = input_ids.size(1)
-        T_pad = -(-T // self.pad_to) * self.pad_to
+    def __call__(self, input_ids: torch.Tensor, labels: torch.Tensor, loss_scale: float = 1.0,
+                 lengths: Optional[Sequence[int]] = None) -> torch.Tensor:
+        """input_ids / labels [P, T] (right-padded: ids 0, labels -1), `lengths` the true lengths (default T for all).
+        -> the P micro-steps' losses (device tensor [P], finetune/ger.py:278-281); d(loss_scale * sum of them) is ADDED to
+        the bucket."""
+        assert input_ids.dim() == 2 and labels.shape == input_ids.shape
+        P, T = input_ids.shape
+        lengths = [T] * P if lengths is None else [int(n) for n in lengths]
+        assert len(lengths) == P and all(2 <= n <= T for n in lengths)
+        T_pad = -(-max(lengths) // self.pad_to) * self.pad_to
         dev = input_ids.device
         Vw = self.model.cpu_rsqrt_vec_width
-        gkey = (T_pad, Vw)        # the rsqrt-emulation switch is resolved while capturing: part of the key
+        gkey = (P, T_pad, Vw)        # the rsqrt-emulation switch is resolved while capturing: part of the key
         ent = self._graphs.get(gkey)
         if ent is None:
-            st = self._state(T_pad, dev)
+            st = self._state(P, T_pad, dev)
             ent = self._graphs[gkey] = [st, None]
         st = ent[0]
+        W = min(T, T_pad)
         st["ids"].zero_()
-        st["ids"][0, :T].copy_(input_ids[0])
-        st["targets"].fill_(-1)
-        st["targets"][: T - 1].copy_(labels[0, 1:])
-        st["grow"].fill_(loss_scale / max(T - 1, 1))
-        st["inv_count"].fill_(1.0 / max(T - 1, 1))
+        st["ids"][:, :W].copy_(input_ids[:, :W])
+        tg = st["targets"].view(P, T_pad)
+        tg.fill_(-1)
+        tg[:, : W - 1].copy_(labels[:, 1:W])
+        # per sequence: positions >= T_i - 1 carry no target, the loss is the mean over its T_i - 1 positions (Q5)
+        lens_d = torch.tensor(lengths, device=dev)
+        col = torch.arange(T_pad, device=dev).view(1, -1)
+        tg.masked_fill_(col >= (lens_d.view(-1, 1) - 1), -1)
+        st["ids"].masked_fill_(col >= lens_d.view(-1, 1), 0)
+        inv = 1.0 / (lens_d - 1).clamp_min(1).to(torch.float32)
+        st["inv_count"].copy_(inv)
+        st["grow"].view(P, T_pad).copy_((inv * loss_scale).view(-1, 1).expand(P, T_pad))
         if Vw:
-            st["tail"].zero_()
-            st["tail"][T // Vw * Vw:T].fill_(1)
+            # Q11: a micro-batch-1 call of the reference has T_i rows; its rows past the last whole vector take the scalar loop
+            st["tail"].view(P, T_pad).copy_(((col >= (lens_d // Vw * Vw).view(-1, 1)) & (col < lens_d.view(-1, 1))).to(torch.uint8))
         if ent[1] is None:
             # warm-up outside capture (allocations, lazy initialisation), with its gradient contribution undone
             keep = self.bucket.flat.clone()

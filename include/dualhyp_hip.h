@@ -115,12 +115,24 @@ int dh_linear_qkv_rope_cache_bf16(const dh_bf16* x, const dh_bf16* w, int M, int
 /* fp32 partial sums for the fused decode consumers below (M <= 4096 rows, weight streaming):
  *   y32[p][m][n] = sum over K-slice p of x[m,:] . W'[n,:],  W' = [w (n_main rows) ; w_ext (n_ext rows)]
  * y32: [ksplit][M][n_main+n_ext] fp32.  w_ext is the rank-padded LoRA A (so x·A^T comes out of the
- * same pass over x as x·W^T and never needs its own launch).  K %% 32 == 0, rows %% 16 == 0. */
+ * same pass over x as x·W^T and never needs its own launch).  K %% 32 == 0, rows %% 16 == 0.
+ *
+ * K-SLICE COMBINE ORDER of the decode family (round 3; one order for every row count, so a row's bits do not depend on
+ * how many rows are decoded with it): a slice is one fp32 chain of v_mfma_f32_16x16x32_bf16 from zero, k ascending;
+ * ADJACENT slices are added in pairs, (s0 + s1), (s2 + s3), ..., an unpaired last slice stands alone; the pair sums are
+ * added in index order.  Producers emit either the slices (dh_linear_partial_bf16: consumers take them with pairs = 1)
+ * or the pair sums (dh_linear_partial_pairs_bf16: pairs = 0, half the bytes) or the total (dh_linear_chain_bf16:
+ * n_part = 1). */
 int dh_linear_partial_bf16(const dh_bf16* x, const dh_bf16* w, const dh_bf16* w_ext, float* y32,
                            int M, int n_main, int n_ext, int K, int ksplit, void* stream);
-/* The ksplit partial sums of dh_linear_partial_bf16 added in slice order, in one launch (tiled kernel, for at least
- * dh_set_tuning(7, min_rows) rows — default 1280, below that the K-sliced kernel is faster): y32 [M][n_main+n_ext] fp32, bit-identical to adding the partials
- * p = 0..ksplit-1 sequentially in fp32.  Consumers take it with n_part = 1.  Needs K %% 64 == 0 and
+/* The PAIR SUMS of those ksplit slices, y32: [(ksplit+1)/2][M][n_main+n_ext] fp32, from a tiled split-K kernel (128-row
+ * tiles, both operands through LDS, one block per tile and slice pair): y32[j] = slice 2j + slice 2j+1, bit-identical
+ * to adding the two partials of dh_linear_partial_bf16.  The decode GEMMs of more than 128 rows (several batches decoded
+ * jointly).  Needs K %% 64 == 0, K-slices of 8 or 16 k-steps (ceil(K/32/ksplit)), whole slices. */
+int dh_linear_partial_pairs_bf16(const dh_bf16* x, const dh_bf16* w, const dh_bf16* w_ext, float* y32, int M,
+                                 int n_main, int n_ext, int K, int ksplit, void* stream);
+/* The ksplit slices combined in the family's order (pairs, then pair sums in index order) in one launch (tiled kernel,
+ * full K per block): y32 [M][n_main+n_ext] fp32.  Consumers take it with n_part = 1.  Needs K %% 64 == 0 and
  * K-slices of 8 or 16 k-steps (ceil(K/32/ksplit)); other shapes return an error. */
 int dh_linear_chain_bf16(const dh_bf16* x, const dh_bf16* w, const dh_bf16* w_ext, float* y32, int M,
                          int n_main, int n_ext, int K, int ksplit, void* stream);
@@ -129,9 +141,10 @@ int dh_linear_chain_bf16(const dh_bf16* x, const dh_bf16* w, const dh_bf16* w_ex
  * ger/model.py:185-186, ger/rmsnorm.py:17-21 in one pass:
  *   h = bf16(bf16(sum_p h32[p]) + bf16(bf16(xa . B^T) * s)) ; x_out = bf16(x_resid + h) ;
  *   xn_out = RMSNorm(x_out; w_norm, eps)      (row_tail: see dh_rmsnorm_bf16)
- * h32: [n_part][rows][d+n_ext] fp32 from dh_linear_partial_bf16, xa = bf16 of columns [d, d+16).
+ * h32: [n_part][rows][d+n_ext] fp32 partials, xa = bf16 of columns [d, d+16); pairs != 0: the partials are SLICES
+ * (added in adjacent pairs first), pairs == 0: they are pair sums or the total (added in index order).
  * lora_b == NULL: no LoRA (n_ext = 0).  x_out may alias x_resid. */
-int dh_finish_norm_bf16(const float* h32, int n_part, int rows, int d, int n_ext,
+int dh_finish_norm_bf16(const float* h32, int n_part, int pairs, int rows, int d, int n_ext,
                         const dh_bf16* lora_b, float lora_scale, const dh_bf16* x_resid,
                         const dh_bf16* w_norm, dh_bf16* x_out, dh_bf16* xn_out, float eps,
                         const uint8_t* row_tail, void* stream);
@@ -159,8 +172,8 @@ int dh_attn_decode_bf16(const dh_bf16* q, const dh_bf16* k_cache, const dh_bf16*
  * finish the q/k/v LoRA from the fp32 partials of dh_linear_partial_bf16 (columns
  * [qkv_dim, qkv_dim+48) = x.A^T; contiguous [Q|K|V] delta, quirk Q2), rotate q and k at position
  * kv_len-1, append k / v to the caches, attend keys 0..kv_len-1 (split over 8 waves, combined in
- * LDS; the new key is merged from registers), write y [n_seq, n_head*hs]. */
-int dh_attn_decode_fused_bf16(const float* qkv32, int n_part, int n_seq, int qkv_dim, int n_ext,
+ * LDS; the new key is merged from registers), write y [n_seq, n_head*hs].  n_part / pairs: as dh_finish_norm_bf16. */
+int dh_attn_decode_fused_bf16(const float* qkv32, int n_part, int pairs, int n_seq, int qkv_dim, int n_ext,
                               const dh_bf16* lora_b, float lora_scale, int split0, int split1,
                               const dh_bf16* cos, const dh_bf16* sin, const int32_t* seq_slot,
                               const int32_t* kv_len, dh_bf16* k_cache, dh_bf16* vT_cache,

@@ -221,8 +221,8 @@ def test_linear_decode_shapes(dev, M, d, I, r):
     check_ulp(got, sc * (F.linear(x, W) + bi), 2, 0.01, "decode adapter")
 
 
-@pytest.mark.parametrize("M", [33, 100, 256])
-@pytest.mark.parametrize("N,n_ext,K,ks", [(2560, 48, 2048, 8), (2048, 0, 5632, 11), (384, 16, 256, 1), (256, 16, 384, 2)])
+@pytest.mark.parametrize("M", [33, 100, 256, 640])
+@pytest.mark.parametrize("N,n_ext,K,ks", [(2560, 48, 2048, 8), (2048, 0, 5632, 11), (2048, 16, 2048, 8), (384, 16, 256, 1), (256, 16, 384, 2)])
 def test_linear_partial_wide_rows(dev, M, N, n_ext, K, ks):
     """Several 32-row groups in one launch (joint decode of several batches): every group's partial
     sums are bit-identical to the same rows in a launch of their own."""
@@ -238,21 +238,42 @@ def test_linear_partial_wide_rows(dev, M, N, n_ext, K, ks):
     ref = x.float() @ torch.cat([W, A]).float().T if n_ext else x.float() @ W.float().T
     got = wide.sum(0)
     assert (got - ref).abs().max().item() <= 1e-3 * ref.abs().max().item() + 1e-4
-    # the tiled kernel (gemm_dt.hip) delivers the partials already added, in slice order, bit for bit
-    if M >= 65 and K % 64 == 0 and (K // 32 + ks - 1) // ks in (8, 16):
-        seq = wide[0].clone()
-        for p in range(1, ks):
-            seq = seq + wide[p]
+    # the tiled kernels (gemm_dt.hip) deliver the same slices already combined, bit for bit, in the decode family's ONE
+    # order (include/dualhyp_hip.h): adjacent slices in pairs, pair sums in index order — the split-K kernel emits the
+    # pair sums (what every decode step above 128 rows runs), the chain kernel the total
+    if K % 64 == 0 and (K // 32 + ks - 1) // ks in (8, 16):
+        pair_sums = torch.stack([wide[i] + wide[i + 1] if i + 1 < ks else wide[i] for i in range(0, ks, 2)])
         from dualhyp_amd import _lib
-        _lib.load().dh_set_tuning(7, 65)
-        try:
-            chain = ops.linear_chain(x, W, A, ksplit=ks)
-        finally:
-            _lib.load().dh_set_tuning(7, 1280)
-        assert torch.equal(chain, seq), "tiled chain sum differs from the ordered sum of the streamed partials"
+        for wn in (2, 4, 0):                    # 128 x 128 tiles on 4 waves, 128 x 256 on 8, the default choice
+            _lib.load().dh_set_tuning(17, wn)
+            try:
+                pairs = ops.linear_partial_pairs(x, W, A, ksplit=ks)
+            finally:
+                _lib.load().dh_set_tuning(17, 0)
+            assert pairs.shape == ((ks + 1) // 2, M, N + n_ext)
+            assert torch.equal(pairs, pair_sums), f"split-K tiles (wn={wn}): pair sums differ from the streamed slices added in pairs"
+        total = ops.combine_partials(wide, pairs=True)
+        assert torch.equal(total, ops.combine_partials(pair_sums, pairs=False))
+        if M >= 65:
+            _lib.load().dh_set_tuning(7, 65)
+            try:
+                chain = ops.linear_chain(x, W, A, ksplit=ks)
+            finally:
+                _lib.load().dh_set_tuning(7, 1280)
+            assert torch.equal(chain, total), "tiled chain sum differs from the family's combine order of the streamed slices"
+        # the consumers: slices (pairs flag) and pair sums give the same bits
+        if N == 2048 and n_ext == 0:
+            xres = U((M, N), 1.0, f"wr{M}").to(dev)
+            wn_ = (1 + U((N,), 0.25, "wwn").float()).bfloat16().to(dev)
+            a = ops.finish_norm(wide, N, xres, wn_, 1e-5, pairs=True)
+            b = ops.finish_norm(pair_sums, N, xres, wn_, 1e-5, pairs=False)
+            c = ops.finish_norm(total.unsqueeze(0), N, xres, wn_, 1e-5, pairs=False)
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[0], c[0]) and torch.equal(a[1], c[1])
     else:
         with pytest.raises(Exception):
             ops.linear_chain(x, W, A, ksplit=ks)
+        with pytest.raises(Exception):
+            ops.linear_partial_pairs(x, W, A, ksplit=ks)
 
 
 @pytest.mark.parametrize("d,I,V", [(2048, 5632, 32000), (256, 384, 256), (512, 768, 512)])

@@ -67,9 +67,11 @@ for (M, d, I) in [(256, 2048, 5632), (1024, 2048, 5632), (100, 512, 768)]:
         wq = rn(d + 512, d) * 0.1
         ks = (d // 32 + 7) // 8
         parts = ops.linear_partial(x, wq, A, ksplit=ks)
-        seq = parts[0].clone()
-        for p in range(1, ks):
-            seq = seq + parts[p]
+        seq = ops.combine_partials(parts, pairs=True)     # the decode family's order: adjacent pairs, then pair sums in turn
+        for wn in (2, 4):
+            lib.dh_set_tuning(17, wn)
+            check(f"split-K pairs(wn {wn}) vs partials M={M} d={d} it={it}", ops.combine_partials(ops.linear_partial_pairs(x, wq, A, ksplit=ks), pairs=False), seq)
+        lib.dh_set_tuning(17, 0)
         lib.dh_set_tuning(7, 65)
         for st in (2, 4):
             lib.dh_set_tuning(8, st)
