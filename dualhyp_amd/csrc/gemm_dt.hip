@@ -299,7 +299,7 @@ int dh_pairs_tiled(const bf16_t* x, const bf16_t* w, const bf16_t* w_ext, float*
     DtArgs a{x, w, w_ext ? w_ext : w, y32, nullptr, nullptr, nullptr, M, N, K, n_main, kps, kps};   // kps k-steps = kps/2 stages per slice, two slices per block
     const int m_tiles = cdiv(M, TB);
     const int wide_blocks = m_tiles * cdiv(N, 256) * ny;
-    const bool wide = g_pairs_wn ? g_pairs_wn == 4 : wide_blocks >= 200;
+    const bool wide = g_pairs_wn ? g_pairs_wn == 4 : wide_blocks >= 160;   // 640 rows: qkv' 220, proj' 180, mlp' 240 blocks of 128 x 256
     if (wide) return launch_dt_n<4, 3, 4>(a, m_tiles * cdiv(N, 256), s, ny);
     const int blocks = m_tiles * cdiv(N, TB);
     return blocks * ny > 256 ? launch_dt_n<4, 2>(a, blocks, s, ny) : launch_dt_n<4, 4>(a, blocks, s, ny);

@@ -511,7 +511,10 @@ bool dh_chain_ok(int M, int n_main, int n_ext, int K, int ksplit) {
            N % 4 == 0 && n_main % ROWS == 0 && n_ext % ROWS == 0;
 }
 
-int g_pairs_min_rows = 129;   // partial-sum GEMMs of at least this many rows take the tiled split-K kernel (dh_set_tuning key 18)
+// partial-sum GEMMs of at least this many rows take the tiled split-K kernel (dh_set_tuning key 18).  tools/sweep_pairs.py,
+// us (slices | pair sums): 160 rows qkv' 11.2 | 12.5, mlp' 15.1 | 19.3; 256 rows 12.9 | 12.8, 18.9 | 20.0; 384 rows 17.0 | 13.5,
+// 25.3 | 23.1; 640 rows 20.7 | 16.0, 30.2 | 24.3; 2048 rows 55.6 | 42.2, 81.5 | 74.0 — and the consumers read half the bytes
+int g_pairs_min_rows = 288;
 bool dh_pairs_ok(int M, int n_main, int n_ext, int K, int ksplit) {
     const int nks = K / 32, kps = (nks + ksplit - 1) / ksplit, N = n_main + n_ext;
     return g_skinny_variant == 1 && M >= g_pairs_min_rows && K % 64 == 0 && (kps == 8 || kps == 16) && ksplit * kps == nks &&

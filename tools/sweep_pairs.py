@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Decode partial-sum GEMMs at the driver's 640 rows (and neighbours): K-sliced streaming kernel (slices) against the tiled
 split-K kernel (pair sums, 128 x 128 and 128 x 256 tiles), plus the consumers on either input (GPU box)."""
-import sys, torch
-sys.path.insert(0, ".")
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from dualhyp_amd import ops, _lib
 from tune_decode_common import bench
 lib = _lib.load()
