@@ -47,10 +47,26 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(
     const bf16_t* __restrict__ dout, const bf16_t* __restrict__ qT, const bf16_t* __restrict__ doT,
     const float* __restrict__ lse, const float* __restrict__ dsum, const int32_t* __restrict__ q_start,
     const int32_t* __restrict__ q_len, const int32_t* __restrict__ pad_start, bf16_t* __restrict__ dk,
-    bf16_t* __restrict__ dv, int n_head, int n_groups, int n_pad, float scale) {
+    bf16_t* __restrict__ dv, int n_head, int n_groups, int n_pad, float scale, int nt, int n_seq) {
     constexpr int KS = HS / 16, DT = HS / 32;
     extern __shared__ __attribute__((aligned(16))) float red[];   // [waves][2][DT][16 regs][64 lanes]
-    const int seq = blockIdx.z, g = blockIdx.y, kt = blockIdx.x;
+    // 1-D grid, XCD-aware (blocks go round-robin over the 8 XCDs): all key tiles of a (group, sequence) pair run on ONE XCD,
+    // so the pair's transposed q / dO copies (64 d-rows x 1.1 KB, strided by the PACKED token count) stay in that XCD's
+    // 4 MiB L2.  With 16 packed sequences the row-major walk had every XCD touch every pair (16 MB per L2): each 8-byte
+    // fragment piece then fetched its own 128-B line from the fabric and the kernel ran 10x longer than the forward.
+    int seq, g, kt;
+    {
+        const int np = n_groups * n_seq;
+        if (np >= 8) {
+            const int b = blockIdx.x, j = b >> 3, pair = (b & 7) + 8 * (j / nt);
+            if (pair >= np) return;
+            kt = j % nt; g = pair % n_groups; seq = pair / n_groups;
+        } else {
+            const int b = blockIdx.x;
+            kt = b % nt; g = (b / nt) % n_groups; seq = b / (nt * n_groups);
+            if (seq >= n_seq) return;
+        }
+    }
     const int len = q_len[seq];
     if (kt * 32 >= len) return;
     const int qs = q_start[seq], ps = pad_start[seq];
@@ -162,9 +178,17 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ dout, const bf16_t* __restrict__ kT, const float* __restrict__ lse,
     const float* __restrict__ dsum, const int32_t* __restrict__ q_start, const int32_t* __restrict__ q_len,
-    const int32_t* __restrict__ pad_start, bf16_t* __restrict__ dq, int n_head, int n_groups, int n_pad, float scale) {
+    const int32_t* __restrict__ pad_start, bf16_t* __restrict__ dq, int n_head, int n_groups, int n_pad, float scale, int nt,
+    int n_seq) {
     constexpr int KS = HS / 16, DT = HS / 32;
-    const int seq = blockIdx.z, head = blockIdx.y, qt = blockIdx.x;
+    // as the dkdv kernel: a (head, sequence) pair's query tiles share one XCD (its K^T copy and K / V rows stay in that L2);
+    // the long tiles (large qt: most key tiles) first
+    int seq, head, qt;
+    {
+        const int np = n_head * n_seq, b = blockIdx.x, j = b >> 3, pair = (b & 7) + 8 * (j / nt);
+        if (pair >= np) return;
+        qt = nt - 1 - j % nt; head = pair % n_head; seq = pair / n_head;
+    }
     const int len = q_len[seq];
     if (qt * 32 >= len) return;
     const int qs = q_start[seq], ps = pad_start[seq];
@@ -272,19 +296,21 @@ extern "C" int dh_attn_bwd_bf16(const dh_bf16* q, const dh_bf16* k, const dh_bf1
     const int nt = cdiv(max_q_len, 32), qpk = n_head / n_groups;
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = (size_t)qpk * 2 * (hs / 32) * 16 * 64 * sizeof(float);
+    const int np_kv = n_groups * n_seq, np_q = n_head * n_seq;
+    const int grid_kv = np_kv >= 8 ? 8 * cdiv(np_kv, 8) * nt : np_kv * nt, grid_q = 8 * cdiv(np_q, 8) * nt;
     if (hs == 64) {
         DH_MAX_LDS_ONCE(attn_bwd_dkdv_kernel<64>, 160 * 1024);
-        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64>), dim3(nt, n_groups, n_seq), dim3(64 * qpk), lds, s, q, k, v, dout, qT, doT,
-                           lse, dsum, q_start, q_len, pad_start, dk, dv, n_head, n_groups, n_pad, scale);
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), dim3(nt, n_head, n_seq), dim3(64), 0, s, q, k, v, dout, kT, lse, dsum,
-                           q_start, q_len, pad_start, dq, n_head, n_groups, n_pad, scale);
+        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64>), dim3(grid_kv), dim3(64 * qpk), lds, s, q, k, v, dout, qT, doT,
+                           lse, dsum, q_start, q_len, pad_start, dk, dv, n_head, n_groups, n_pad, scale, nt, n_seq);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), dim3(grid_q), dim3(64), 0, s, q, k, v, dout, kT, lse, dsum,
+                           q_start, q_len, pad_start, dq, n_head, n_groups, n_pad, scale, nt, n_seq);
     } else {
         DH_CHECK(lds <= 160 * 1024, "dh_attn_bwd_bf16: too many heads per group for head_size 128");
         DH_MAX_LDS_ONCE(attn_bwd_dkdv_kernel<128>, 160 * 1024);
-        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128>), dim3(nt, n_groups, n_seq), dim3(64 * qpk), lds, s, q, k, v, dout, qT, doT,
-                           lse, dsum, q_start, q_len, pad_start, dk, dv, n_head, n_groups, n_pad, scale);
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<128>), dim3(nt, n_head, n_seq), dim3(64), 0, s, q, k, v, dout, kT, lse, dsum,
-                           q_start, q_len, pad_start, dq, n_head, n_groups, n_pad, scale);
+        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128>), dim3(grid_kv), dim3(64 * qpk), lds, s, q, k, v, dout, qT, doT,
+                           lse, dsum, q_start, q_len, pad_start, dk, dv, n_head, n_groups, n_pad, scale, nt, n_seq);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<128>), dim3(grid_q), dim3(64), 0, s, q, k, v, dout, kT, lse, dsum,
+                           q_start, q_len, pad_start, dq, n_head, n_groups, n_pad, scale, nt, n_seq);
     }
     DH_LAUNCH_CHECK();
     return 0;

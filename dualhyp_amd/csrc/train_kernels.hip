@@ -159,10 +159,21 @@ __global__ __launch_bounds__(256) void tn_accum_kernel(const bf16_t* __restrict_
 // rank, padded to 16 or 3 x 16): lanes run along the large one (coalesced loads of its operand, coalesced
 // stores), 16 values of the small one sit in registers (its operand row is a 32-byte broadcast), the four
 // waves of a block deal the tokens among them and meet in LDS.  LARGE_IS_M: out[m = large][n = small].
+// PACKED micro-batches (round 3: P x 560 tokens per launch) make the token loop the long dimension: the grid's z splits the
+// tokens into chunks of `tchunk`; with gridDim.z > 1 a block writes its chunk's plain fp32 sums to part[z][M][N] and
+// tn_reduce_kernel adds the chunks in index order (deterministic, no atomics), applies `scale` and accumulates.
 template <bool LARGE_IS_M>
 __global__ __launch_bounds__(1024) void tn_accum_wide_kernel(const bf16_t* __restrict__ a, int lda, const bf16_t* __restrict__ b,
                                                              int ldb, float* __restrict__ out, int ldo, int T, int M, int N,
-                                                             float scale, int accumulate) {
+                                                             float scale, int accumulate, int tchunk) {
+    if (gridDim.z > 1) {
+        const int t_begin = blockIdx.z * tchunk;
+        a += (size_t)t_begin * lda;
+        b += (size_t)t_begin * ldb;
+        T = min(T - t_begin, tchunk);
+        out += (size_t)blockIdx.z * M * N;      // part[z], dense [M][N]
+        ldo = N; scale = 1.f; accumulate = 0;
+    }
     constexpr int NWV = 16, UN = 4;      // waves per block (tokens dealt over them), tokens in flight per wave
     __shared__ float red[NWV][16][64];   // 64 KiB
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -212,6 +223,17 @@ __global__ __launch_bounds__(1024) void tn_accum_wide_kernel(const bf16_t* __res
             *p = (accumulate ? *p : 0.f) + scale * v;
         }
     }
+}
+
+// out[m][n] = (accumulate ? out : 0) + scale * (part[0] + part[1] + ... in index order)
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, int nz, float* __restrict__ out, int ldo,
+                                                        int M, int N, float scale, int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * N) return;
+    float s = 0.f;
+    for (int z = 0; z < nz; ++z) s += part[(size_t)z * M * N + i];
+    float* o = out + (size_t)(i / N) * ldo + i % N;
+    *o = (accumulate ? *o : 0.f) + scale * s;
 }
 
 // D[t][h] = sum_d dO[t][h][d] * O[t][h][d]   (softmax backward row term)
@@ -274,22 +296,31 @@ extern "C" int dh_qkv_rope_bwd_bf16(const dh_bf16* dq, const dh_bf16* dk, const 
     return 0;
 }
 
+constexpr int TN_CHUNK = 512;     // tokens per block of the split form
+extern "C" int64_t dh_tn_accum_work_bytes(int T, int M, int N) {
+    return T > 2 * TN_CHUNK ? (int64_t)cdiv(T, TN_CHUNK) * M * N * (int64_t)sizeof(float) : 0;
+}
+
 extern "C" int dh_tn_accum_f32(const dh_bf16* a, int lda, const dh_bf16* b, int ldb, float* out, int ldo, int T, int M,
-                               int N, float scale, int accumulate, void* stream) {
+                               int N, float scale, int accumulate, void* work, void* stream) {
     DH_CHECK(a && b && out && T >= 0 && M > 0 && N > 0, "dh_tn_accum_f32: bad argument");
     hipStream_t st = (hipStream_t)stream;
     // the small operand is read as aligned 16-byte runs
     const bool n_small = N % 16 == 0 && N <= 64 && M >= 64 && ldb % 8 == 0 && ((uintptr_t)b & 15) == 0;
     const bool m_small = M % 16 == 0 && M <= 64 && N >= 64 && lda % 8 == 0 && ((uintptr_t)a & 15) == 0;
-    if (n_small) {
-        hipLaunchKernelGGL(tn_accum_wide_kernel<true>, dim3(cdiv(M, 64), N / 16), dim3(1024), 0, st, a, lda, b, ldb, out, ldo, T, M,
-                           N, scale, accumulate);
-        DH_LAUNCH_CHECK();
-        return 0;
-    }
-    if (m_small) {
-        hipLaunchKernelGGL(tn_accum_wide_kernel<false>, dim3(cdiv(N, 64), M / 16), dim3(1024), 0, st, a, lda, b, ldb, out, ldo, T, M,
-                           N, scale, accumulate);
+    if (n_small || m_small) {
+        // long token loops (packed micro-batches) are split over the grid's z when the caller brought scratch
+        const int nz = work != nullptr && T > 2 * TN_CHUNK ? cdiv(T, TN_CHUNK) : 1;
+        float* dst = nz > 1 ? (float*)work : out;
+        if (n_small)
+            hipLaunchKernelGGL(tn_accum_wide_kernel<true>, dim3(cdiv(M, 64), N / 16, nz), dim3(1024), 0, st, a, lda, b, ldb, dst, ldo,
+                               T, M, N, scale, accumulate, TN_CHUNK);
+        else
+            hipLaunchKernelGGL(tn_accum_wide_kernel<false>, dim3(cdiv(N, 64), M / 16, nz), dim3(1024), 0, st, a, lda, b, ldb, dst, ldo,
+                               T, M, N, scale, accumulate, TN_CHUNK);
+        if (nz > 1)
+            hipLaunchKernelGGL(tn_reduce_kernel, dim3(cdiv(M * N, 256)), dim3(256), 0, st, (const float*)work, nz, out, ldo, M, N, scale,
+                               accumulate);
         DH_LAUNCH_CHECK();
         return 0;
     }

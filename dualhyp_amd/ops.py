@@ -423,8 +423,11 @@ def tn_accum(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, scale: float =
     assert a.stride(1) == 1 and b.stride(1) == 1 and out.dtype == torch.float32 and out.stride(1) == 1
     T, M = a.shape
     N = b.size(1)
-    check(_lib.load().dh_tn_accum_f32(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0),
-                                      T, M, N, float(scale), int(accumulate), _stream()))
+    lib = _lib.load()
+    wb = lib.dh_tn_accum_work_bytes(T, M, N)       # packed micro-batches: the token loop is split over the grid
+    work = torch.empty(wb // 4, dtype=torch.float32, device=a.device) if wb else None
+    check(lib.dh_tn_accum_f32(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0),
+                              T, M, N, float(scale), int(accumulate), _p(work), _stream()))
 
 
 def attn_bwd(q, k, v, out, dout, lse, q_start, q_len, max_q_len: int, lens: Optional[Sequence[int]] = None):

@@ -197,9 +197,12 @@ int dh_rmsnorm_bwd_bf16(const dh_bf16* dy, const dh_bf16* x, const dh_bf16* w, c
 int dh_qkv_rope_bwd_bf16(const dh_bf16* dq, const dh_bf16* dk, const dh_bf16* dv, const dh_bf16* cos,
                          const dh_bf16* sin, const int32_t* tok_pos, dh_bf16* dqkv, int n_tok,
                          int n_head, int n_groups, int hs, void* stream);
-/* out[M,N] (+)= scale * a[T,M]^T . b[T,N]   (LoRA dA / dB: contraction over tokens), fp32 out */
+/* out[M,N] (+)= scale * a[T,M]^T . b[T,N]   (LoRA dA / dB: contraction over tokens), fp32 out.  work (nullable):
+ * >= dh_tn_accum_work_bytes(T, M, N) bytes of scratch; with it a long token loop (packed micro-batches: T > 1024) is split
+ * into 512-token chunks over the grid and the chunk sums are added in index order by a second launch (deterministic). */
+int64_t dh_tn_accum_work_bytes(int T, int M, int N);
 int dh_tn_accum_f32(const dh_bf16* a, int lda, const dh_bf16* b, int ldb, float* out, int ldo, int T,
-                    int M, int N, float scale, int accumulate, void* stream);
+                    int M, int N, float scale, int accumulate, void* work, void* stream);
 /* out[row] = sum_d a[row,d]*b[row,d]   (softmax-backward row term D = rowsum(dO*O)) */
 int dh_rowdot_f32(const dh_bf16* a, const dh_bf16* b, float* out, int64_t rows, int hs, void* stream);
 /* src [n_tok, heads, hs] -> dst [heads, hs, n_pad], sequence i placed at pad_start[i] (multiple of 32) */

@@ -48,6 +48,17 @@ def test_swiglu_rmsnorm_tn_bwd():
     want = 1 + 0.5 * a[:, 16:32].float().T @ b.float()
     assert (out.cpu() - want).abs().max().item() <= 1e-4 * want.abs().max().item()
     ops.tn_accum(a.to(DEV)[:, 16:32], b.to(DEV), out, scale=2.0, accumulate=False)
+    # packed micro-batches: a long token loop is split over the grid in 512-token chunks, summed in order (both orientations)
+    for T in (1025, 4480):
+        a2, b2 = U((T, 48), 1.0, f"ta{T}").to(DEV), U((T, 320), 1.0, f"tb{T}").to(DEV)
+        for A_, B_ in ((a2[:, 16:32], b2), (b2, a2[:, :48])):
+            o = torch.full((A_.size(1), B_.size(1)), 3.0, dtype=torch.float32, device=DEV)
+            ops.tn_accum(A_, B_, o, scale=0.25, accumulate=True)
+            w = 3.0 + 0.25 * (A_.float().T @ B_.float())
+            assert (o - w).abs().max().item() <= 2e-5 * w.abs().max().item() + 1e-4, (T, tuple(o.shape))
+            o2 = torch.empty_like(o)
+            ops.tn_accum(A_, B_, o2, scale=0.25, accumulate=False)
+            assert torch.equal(o2 + 3.0, o) or (o2 + 3.0 - o).abs().max().item() <= 1e-5 * w.abs().max().item()
     assert (out.cpu() - 2 * (want - 1) / 0.5).abs().max().item() <= 1e-3
 
 
