@@ -397,14 +397,14 @@ def bench_finetune(a, wl, cfg, model, dev, rank: int, world: int, rehearsal: boo
         torch.cuda.synchronize()
 
     def opt_step(k):
-        loss = None
+        losses = []
         for i in range(per_rank // PACK):
             j = (k * (per_rank // PACK) + i) % len(mine)
-            loss = step_fn(mine[j], labs[j], 1.0 / per_rank)   # mean over this rank's micro-batches; all_reduce_mean then averages the ranks (as fit() does)
+            losses.append(step_fn(mine[j], labs[j], 1.0 / per_rank))   # mean over this rank's micro-batches; all_reduce_mean then averages the ranks (as fit() does)
         bucket.all_reduce_mean()
         opt.step()
         bucket.zero()
-        return loss
+        return torch.cat(losses)           # this rank's per-utterance losses of the step
     for k in range(max(a.warmup, 1)):
         opt_step(k)
     barrier()
@@ -413,10 +413,14 @@ def bench_finetune(a, wl, cfg, model, dev, rank: int, world: int, rehearsal: boo
         last = opt_step(k)
     barrier()
     dt = time.perf_counter() - t0
+    mean_loss = last.mean().to(torch.float64)
     if world > 1:
         tt = torch.tensor([dt], device="cpu" if rehearsal else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        ml = mean_loss.cpu() if rehearsal else mean_loss     # the global batch's mean loss: the same 32 utterances whatever the world size
+        dist.all_reduce(ml, op=dist.ReduceOp.SUM)
+        mean_loss = ml / world
     if rank == 0:
         # fwd 2NT + dX 2NT over the frozen base (no dW), LoRA 6 x 4.5M x T, attention fwd+bwd
         d, I = cfg.n_embd, cfg.intermediate_size
@@ -437,7 +441,7 @@ def bench_finetune(a, wl, cfg, model, dev, rank: int, world: int, rehearsal: boo
             "roofline": {"bound": "mfma", "kernel": wl["kernel"], "achieved": achieved, "peak": wl["peak"], "unit": "TFLOP/s",
                          "frac": achieved / wl["peak"], "traffic": None, "flop_per_utterance": flop_utt,
                          "note": "algorithmic FLOP of the whole micro-step / wall time per GPU: kernels inside a hipGraph replay cannot be bracketed by events"},
-            "last_loss": float(last.mean().item()), "cpu_baseline": None}), flush=True)
+            "last_loss": float(last.mean().item()), "mean_loss_last_step": float(mean_loss.item()), "cpu_baseline": None}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

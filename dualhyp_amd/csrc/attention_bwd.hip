@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const bf16_t* __rest
     }
 }
 
-template <int HS>
+template <int HS, int QPKT>   // QPKT <= query heads per group (block = 64 x that many threads): sizes the per-thread totals
 __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ dout, const bf16_t* __restrict__ qT, const bf16_t* __restrict__ doT,
@@ -149,20 +149,50 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(
             }
         }
     }
-    // ---- sum the heads of the group (LDS), then write dK (scaled) and dV: lane col = key, rows = d
-    float* mine = red + (size_t)wave * 2 * DT * 16 * 64;
+    // ---- sum the heads of the group (LDS), then write dK (scaled) and dV: lane col = key, rows = d.  The waves pass
+    // through LDS FOUR at a time (64 KiB at hs 64 instead of 128: two blocks per CU, twice the waves to hide the loop's
+    // global-load latency); the sum still runs over the heads in index order (w0 + w1 + ... from zero).
+    constexpr int PER_WAVE = 2 * DT * 16 * 64;                 // floats a wave contributes
+    // values per thread (8 at hs 64 with 8 heads per group); QPKT 1 = fewer than four heads per group: a single pass,
+    // whose totals need not outlive the loop — NV 1 and a strided walk instead of 128 live registers
+    constexpr int NV = QPKT == 1 ? 1 : PER_WAVE / (64 * QPKT);
+    float tot[NV];
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            mine[((0 * DT + dt) * 16 + r) * 64 + lane] = dkT[dt][r];
-            mine[((1 * DT + dt) * 16 + r) * 64 + lane] = dvT[dt][r];
-        }
-    __syncthreads();
+    for (int i = 0; i < NV; ++i) tot[i] = 0.f;
     const int nw = q_per_kv;
-    for (int it = threadIdx.x; it < 2 * DT * 16 * 64; it += blockDim.x) {
-        float sum = 0.f;
-        for (int w = 0; w < nw; ++w) sum += red[(size_t)w * 2 * DT * 16 * 64 + it];
+    for (int w0 = 0; w0 < nw; w0 += 4) {
+        if (w0) __syncthreads();                                // the previous four have been read
+        if (wave >= w0 && wave < w0 + 4) {
+            float* mine = red + (size_t)(wave - w0) * PER_WAVE;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    mine[((0 * DT + dt) * 16 + r) * 64 + lane] = dkT[dt][r];
+                    mine[((1 * DT + dt) * 16 + r) * 64 + lane] = dvT[dt][r];
+                }
+        }
+        __syncthreads();
+        const int cnt = min(4, nw - w0);
+        if (QPKT == 1) break;                                   // nw <= 3: finished below straight from LDS
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int it = threadIdx.x + i * (int)blockDim.x;
+            if (it < PER_WAVE)
+                for (int w = 0; w < cnt; ++w) tot[i] += red[(size_t)w * PER_WAVE + it];
+        }
+    }
+    const int n_it = QPKT == 1 ? (PER_WAVE + (int)blockDim.x - 1) / (int)blockDim.x : NV;
+    for (int i = 0; i < n_it; ++i) {
+        const int it = threadIdx.x + i * (int)blockDim.x;
+        if (it >= PER_WAVE) continue;
+        float sum;
+        if (QPKT == 1) {
+            sum = 0.f;
+            for (int w = 0; w < nw; ++w) sum += red[(size_t)w * PER_WAVE + it];
+        } else {
+            sum = tot[i < NV ? i : 0];
+        }
         const int ln = it & 63, r = (it >> 6) & 15, dt = (it >> 10) % DT, which = it / (DT * 16 * 64);
         const int key = key0 + (ln & 31);
         const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
@@ -295,20 +325,23 @@ extern "C" int dh_attn_bwd_bf16(const dh_bf16* q, const dh_bf16* k, const dh_bf1
     const float scale = 1.0f / sqrtf((float)hs);
     const int nt = cdiv(max_q_len, 32), qpk = n_head / n_groups;
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = (size_t)qpk * 2 * (hs / 32) * 16 * 64 * sizeof(float);
+    const size_t lds = (size_t)(qpk < 4 ? qpk : 4) * 2 * (hs / 32) * 16 * 64 * sizeof(float);   // four waves at a time pass through LDS
     const int np_kv = n_groups * n_seq, np_q = n_head * n_seq;
     const int grid_kv = np_kv >= 8 ? 8 * cdiv(np_kv, 8) * nt : np_kv * nt, grid_q = 8 * cdiv(np_q, 8) * nt;
     if (hs == 64) {
-        DH_MAX_LDS_ONCE(attn_bwd_dkdv_kernel<64>, 160 * 1024);
-        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64>), dim3(grid_kv), dim3(64 * qpk), lds, s, q, k, v, dout, qT, doT,
-                           lse, dsum, q_start, q_len, pad_start, dk, dv, n_head, n_groups, n_pad, scale, nt, n_seq);
+#define DKDV(QT) do { DH_MAX_LDS_ONCE((attn_bwd_dkdv_kernel<64, QT>), 160 * 1024);                                       \
+        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, QT>), dim3(grid_kv), dim3(64 * qpk), lds, s, q, k, v, dout, qT, doT, lse, dsum,  \
+                           q_start, q_len, pad_start, dk, dv, n_head, n_groups, n_pad, scale, nt, n_seq); } while (0)
+        if (qpk == 8) DKDV(8); else if (qpk >= 4) DKDV(4); else DKDV(1);
+#undef DKDV
         hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), dim3(grid_q), dim3(64), 0, s, q, k, v, dout, kT, lse, dsum,
                            q_start, q_len, pad_start, dq, n_head, n_groups, n_pad, scale, nt, n_seq);
     } else {
-        DH_CHECK(lds <= 160 * 1024, "dh_attn_bwd_bf16: too many heads per group for head_size 128");
-        DH_MAX_LDS_ONCE(attn_bwd_dkdv_kernel<128>, 160 * 1024);
-        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128>), dim3(grid_kv), dim3(64 * qpk), lds, s, q, k, v, dout, qT, doT,
-                           lse, dsum, q_start, q_len, pad_start, dk, dv, n_head, n_groups, n_pad, scale, nt, n_seq);
+#define DKDV(QT) do { DH_MAX_LDS_ONCE((attn_bwd_dkdv_kernel<128, QT>), 160 * 1024);                                       \
+        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, QT>), dim3(grid_kv), dim3(64 * qpk), lds, s, q, k, v, dout, qT, doT, lse, dsum,  \
+                           q_start, q_len, pad_start, dk, dv, n_head, n_groups, n_pad, scale, nt, n_seq); } while (0)
+        if (qpk == 8) DKDV(8); else if (qpk >= 4) DKDV(4); else DKDV(1);
+#undef DKDV
         hipLaunchKernelGGL((attn_bwd_dq_kernel<128>), dim3(grid_q), dim3(64), 0, s, q, k, v, dout, kT, lse, dsum,
                            q_start, q_len, pad_start, dq, n_head, n_groups, n_pad, scale, nt, n_seq);
     }

@@ -133,8 +133,9 @@ def test_finetune_harness_writes_reference_checkpoints(tmp_path):
 
 
 def _launch(n, out_path):
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(29500 + os.getpid() % 500), str(ROOT / "tests" / "dp_worker.py"), "--out", str(out_path)]
+    # --standalone: the launcher picks and holds its own rendezvous port on 127.0.0.1 (no fixed-port collisions)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={n}", str(ROOT / "tests" / "dp_worker.py"), "--out", str(out_path)]
     out = subprocess.run(cmd, cwd=ROOT, env=_env(DUALHYP_DP_REHEARSAL="1"), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     return torch.load(out_path)
@@ -157,3 +158,28 @@ def test_data_parallel_equivalence(tmp_path):
     for k in ("WER", "gtms", "post_ST_wer", "post_gtms", "n"):
         assert one["inference"][k] == two["inference"][k], k
     assert one["inference"]["predictions"] == two["inference"]["predictions"] and len(one["inference"]["predictions"]) == 7
+
+
+def test_finetune_bench_two_rank_rehearsal():
+    """BASELINE config 3's bench line through the real launcher path with TWO ranks (both on cuda:0, gloo: gpurun boxes have
+    one GPU) — the only bench where a collective sits inside the timed loop: `bench.py --config finetune-tinyllama --gpus 2`
+    self-launches two fresh rank processes, every rank runs 16 packed micro-batches per optimizer step, the flat LoRA-gradient
+    bucket is all-reduced, AdamW steps.  The global batch's mean loss after two optimizer steps must equal the 1-rank run's
+    (same 32 utterances per step, same averaged gradient): the multi-rank bench really optimises what it describes."""
+    import json
+
+    def run(n):
+        out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--config", "finetune-tinyllama", "--gpus", str(n), "--steps", "2",
+                              "--warmup", "1", "--pack", "8"], cwd=ROOT, env=_env(DUALHYP_BENCH_REHEARSAL="1"), capture_output=True,
+                             text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1
+        return json.loads(lines[0])
+    one, two = run(1), run(2)
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["scaling"] == "strong"
+    assert two["config"]["micro_batches_per_rank_per_step"] == 16 and two["config"]["micro_batches_per_packed_launch"] == 8
+    from conftest import record_parity
+    record_parity("bench_finetune.two_rank_rehearsal", mean_loss_1rank=one["mean_loss_last_step"], mean_loss_2ranks=two["mean_loss_last_step"],
+                  utt_per_s_1rank=one["value"], utt_per_s_2ranks_one_gpu=two["value"])
+    assert abs(one["mean_loss_last_step"] - two["mean_loss_last_step"]) <= 2e-3 * abs(one["mean_loss_last_step"])
