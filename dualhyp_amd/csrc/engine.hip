@@ -234,7 +234,7 @@ int run_layers_fp8(dh_engine* e, const int64_t* ids, int n_tok, int n_seq, int m
         bf16_t* kc = e->kc + (size_t)l * e->cache_layer_elems;
         bf16_t* vtc = e->vtc + (size_t)l * e->cache_layer_elems;
         if ((rc = dh_rmsnorm_quant_fp8(e->x, W.norm_1, nullptr, e->xq, e->xscale, n_tok, d, D.norm_eps, rt, s))) return rc;
-        if (decode && n_tok <= 32) {
+        if (decode && n_tok <= 128) {     // every streaming-class step (fp8_kernel above): one family, no 32-row boundary
             // one launch for rope + cache append + split-KV attention + combine (decode_fused.hip): the QKV product
             // is handed over as its single fp32 "partial" (values already rounded to bf16), no LoRA (merged)
             {

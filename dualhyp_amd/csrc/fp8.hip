@@ -567,9 +567,15 @@ extern "C" int dh_rmsnorm_quant_fp8(const dh_bf16* x, const dh_bf16* w, dh_bf16*
 extern "C" int dh_linear_fp8_f32(const uint8_t* xq, const float* x_scale, const uint8_t* wq, const float* w_scale, float* y32,
                                  int M, int N, int K, void* stream) {
     DH_CHECK(xq && x_scale && wq && w_scale && y32, "dh_linear_fp8_f32: null operand");
-    DH_CHECK(M >= 1 && M <= 32 && N > 0 && K > 0 && K % 128 == 0, "dh_linear_fp8_f32: needs 1 <= M <= 32 and K %% 128 == 0 (M=%d K=%d)", M, K);
+    DH_CHECK(M >= 1 && M <= FP8_STREAM_MAX_ROWS && N > 0 && K > 0 && K % 128 == 0, "dh_linear_fp8_f32: needs 1 <= M <= %d and K %% 128 == 0 (M=%d K=%d)",
+             FP8_STREAM_MAX_ROWS, M, K);
     Fp8Args a{xq, wq, nullptr, reinterpret_cast<bf16_t*>(y32), x_scale, w_scale, nullptr, nullptr, nullptr, nullptr, M, N, K, 0, 0};
-    hipLaunchKernelGGL((gemm_fp8_skinny_kernel<DH_EPI_PLAIN, false, true>), dim3(cdiv(N, ROWS)), dim3(512), 0, (hipStream_t)stream, a);
+    dim3 grid(cdiv(N, ROWS)), block(512);
+    hipStream_t s = (hipStream_t)stream;
+    // row groups as launch_skinny: the same kernel (and bits) as dh_linear_fp8's streaming form, fp32 store
+    if (M <= 32) hipLaunchKernelGGL((gemm_fp8_skinny_kernel<DH_EPI_PLAIN, false, true, 1>), grid, block, 0, s, a);
+    else if (M <= 64) hipLaunchKernelGGL((gemm_fp8_skinny_kernel<DH_EPI_PLAIN, false, true, 2>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((gemm_fp8_skinny_kernel<DH_EPI_PLAIN, false, true, 4>), grid, block, 0, s, a);
     DH_LAUNCH_CHECK();
     return 0;
 }

@@ -293,7 +293,7 @@ int dh_linear_fp8_ex(const uint8_t* xq, const float* x_scale, const uint8_t* wq,
                      int K, int epilogue, const uint8_t* w2q, const float* w2_scale, const dh_bf16* vec_a, const dh_bf16* vec_b,
                      const dh_bf16* resid, int kernel, void* stream);
 
-/* dh_linear_fp8 PLAIN for 1 <= M <= 32 with the bf16-rounded result written as fp32 [M, N]: the single "partial" the
+/* dh_linear_fp8 PLAIN (streaming kernel) for 1 <= M <= 128 with the bf16-rounded result written as fp32 [M, N]: the single "partial" the
  * fused decode-attention kernel (dh_attn_decode_fused_bf16, n_part = 1, no LoRA) consumes. */
 int dh_linear_fp8_f32(const uint8_t* xq, const float* x_scale, const uint8_t* wq, const float* w_scale, float* y32, int M,
                       int N, int K, void* stream);
