@@ -22,6 +22,8 @@
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 
+int g_fp8_tile = 0;   // dh_set_tuning key 19: 0 = by grid size, 128 / 256 = forced tile edge of the tiled fp8 GEMM
+
 namespace {
 
 constexpr float FP8_MAX = 448.0f;
@@ -211,11 +213,20 @@ __device__ __forceinline__ float fp8_finish(float acc, float sc, const Fp8Args& 
 // ------------------------------------------------------------------------------ tiled kernel (M > 32)
 // Same skeleton as gemm.hip's gemm_nt_kernel: C^T tiles (A operand = W rows, B operand = x rows), XCD-aware
 // tile order, NST LDS stages with counted vmcnt.  A stage is one MFMA k-step: 128 k = 128 bytes per row.
-template <int EPI, bool RESID, int NST>
-__global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(Fp8Args a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // NST x (W tile 16 KiB + x tile 16 KiB)
+// WG (waves per tile edge): 2 = 128 x 128 tile on 4 waves, two blocks per CU; 4 (round 3) = 256 x 256 tile on SIXTEEN waves
+// (each still a 64 x 64 wave tile: 64 accumulator registers), one block per CU, two stages of 64 KiB.  The 128-tile stages
+// 32 KiB per 4.2 MFLOP: at the ~65 GB/s a CU takes in by LDS-DMA that caps the kernel near 2.1 PFLOP/s; the 256-tile halves
+// the bytes per FLOP (and the DMA requests per wave), at four waves per SIMD (128 VGPRs: the x fragments are read one at a
+// time instead of four up front).
+template <int EPI, bool RESID, int NST, int WG = 2>
+__global__ __launch_bounds__(WG * WG * 64, WG == 2 ? 2 : 1) void gemm_fp8_kernel(Fp8Args a) {
+    constexpr int BTW = WG * 64;                    // tile edge
+    constexpr int TILE = BTW * BKB;                 // bytes of one operand tile of a stage
+    constexpr int GPW = 8 / WG;                     // 1-KiB row groups (8 rows x 128 B) per wave and operand
+    static_assert(WG == 2 || (WG == 4 && NST == 2), "the 256-tile runs the two-stage loop");
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // NST x (W tile + x tile)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave >> 1, wm = wave & 1;
+    const int wn = wave / WG, wm = wave % WG;
     const int nwg = a.nb_n * a.nb_m;
     int tile;
     {
@@ -223,14 +234,14 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(Fp8Args a) {
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
     const int tm = tile / a.nb_n, tn = tile % a.nb_n;
-    const int m0 = tm * BT;
-    const int n0 = (EPI == DH_EPI_SWIGLU) ? tn * 64 : tn * BT;
+    const int m0 = tm * BTW;
+    const int n0 = (EPI == DH_EPI_SWIGLU) ? tn * (WG * 32) : tn * BTW;
 
-    const uint8_t* srcA[4];
-    const uint8_t* srcB[4];
+    const uint8_t* srcA[GPW];
+    const uint8_t* srcB[GPW];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int R = wave * 4 + j;               // 1-KiB row group: LDS rows R*8 .. R*8+7
+    for (int j = 0; j < GPW; ++j) {
+        const int R = wave * GPW + j;             // 1-KiB row group: LDS rows R*8 .. R*8+7
         const int row = R * 8 + (lane >> 3);
         const int chunk = (lane & 7) ^ swz(row);  // logical 16-B chunk held by this LDS slot
         {
@@ -253,11 +264,11 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(Fp8Args a) {
         }
     }
     auto stage = [&](int buf, int kt) {
-        char* sA = smem + buf * 2 * TILE_BYTES;
-        char* sB = sA + TILE_BYTES;
+        char* sA = smem + buf * 2 * TILE;
+        char* sB = sA + TILE;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int R = wave * 4 + j;
+        for (int j = 0; j < GPW; ++j) {
+            const int R = wave * GPW + j;
             glds16(srcA[j] + (size_t)kt * BKB, sA + R * 1024);
             glds16(srcB[j] + (size_t)kt * BKB, sB + R * 1024);
         }
@@ -279,18 +290,34 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(Fp8Args a) {
         return i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
     };
     auto compute = [&](int buf) __attribute__((always_inline)) {
-        const char* sA = smem + buf * 2 * TILE_BYTES;
-        const char* sB = sA + TILE_BYTES;
-        i32x8 fa[4], fb[4];
+        const char* sA = smem + buf * 2 * TILE;
+        const char* sB = sA + TILE;
+        if constexpr (WG == 2) {
+            i32x8 fa[4], fb[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            fa[i] = frag(sA + offA + i * 2048);
-            fb[i] = frag(sB + offB + i * 2048);
+            for (int i = 0; i < 4; ++i) {
+                fa[i] = frag(sA + offA + i * 2048);
+                fb[i] = frag(sB + offB + i * 2048);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma_fp8(fa[i], fb[j], acc[i][j]);
+        } else {
+            // four waves per SIMD: 128 VGPRs each — the four W fragments up front, the x fragments one (plus one in flight) at a time
+            i32x8 fa[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = frag(sA + offA + i * 2048);
+            i32x8 fb = frag(sB + offB);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                i32x8 nxt = fb;
+                if (j + 1 < 4) nxt = frag(sB + offB + (j + 1) * 2048);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][j] = mfma_fp8(fa[i], fb, acc[i][j]);
+                fb = nxt;
+            }
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = mfma_fp8(fa[i], fb[j], acc[i][j]);
     };
     if constexpr (NST == 2) {
         stage(0, 0);
@@ -506,17 +533,24 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_skinny_kernel(Fp8Args a) {
     }
 }
 
-template <int EPI, bool RESID, int NST>
+template <int EPI, bool RESID, int NST, int WG = 2>
 int launch_tiled_n(const Fp8Args& a, hipStream_t s) {
-    constexpr int lds = NST * 2 * TILE_BYTES;
-    DH_MAX_LDS_ONCE((gemm_fp8_kernel<EPI, RESID, NST>), lds);
-    hipLaunchKernelGGL((gemm_fp8_kernel<EPI, RESID, NST>), dim3(a.nb_n * a.nb_m), dim3(256), lds, s, a);
+    constexpr int lds = NST * 2 * (WG * 64) * BKB;
+    DH_MAX_LDS_ONCE((gemm_fp8_kernel<EPI, RESID, NST, WG>), lds);
+    hipLaunchKernelGGL((gemm_fp8_kernel<EPI, RESID, NST, WG>), dim3(a.nb_n * a.nb_m), dim3(WG * WG * 64), lds, s, a);
     DH_LAUNCH_CHECK();
     return 0;
 }
 
 template <int EPI>
-int launch_tiled(const Fp8Args& a, hipStream_t s) {
+int launch_tiled(Fp8Args a, hipStream_t s) {
+    // 256 x 256 tiles on sixteen waves when they still give every CU two tiles to walk (prefill); the same fp32 chain per
+    // output as the 128-tile (one accumulator, k ascending in steps of 128), so rows stay bit-identical across the choice
+    const int nbm = cdiv(a.M, 256), nbn = EPI == DH_EPI_SWIGLU ? cdiv(a.N, 128) : cdiv(a.N, 256);
+    if (g_fp8_tile ? g_fp8_tile == 256 : nbm * nbn >= 512) {
+        a.nb_m = nbm; a.nb_n = nbn;
+        return a.resid ? launch_tiled_n<EPI, true, 2, 4>(a, s) : launch_tiled_n<EPI, false, 2, 4>(a, s);
+    }
     // as gemm.hip: grids smaller than the chip walk K alone -> 4 stages, one block per CU; else 2 stages, two blocks
     if (a.nb_n * a.nb_m < 384) return a.resid ? launch_tiled_n<EPI, true, 4>(a, s) : launch_tiled_n<EPI, false, 4>(a, s);
     return a.resid ? launch_tiled_n<EPI, true, 2>(a, s) : launch_tiled_n<EPI, false, 2>(a, s);

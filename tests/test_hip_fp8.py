@@ -107,6 +107,21 @@ def test_linear_fp8_matches_the_oracle(M, N, K):
             F.silu(y0) * O.linear_fp8(x, w2q, w2s.view(-1)), tag + "swiglu", max_ulp=4, max_frac=0.025)      # a product of two rounded values: their boundary flips add up
         chk(ops.linear_fp8(xq, xs, wqd, wsd, epilogue=ops.EPI_ADAPTER, scale=dv(sc), bias=dv(bi), kernel=kernel), sc * (y0 + bi), tag + "adapter",
             floor=1.0, max_ulp=4)    # y0 + bias cancels: ulps at max(|a|, |b|, rms)
+    if M > 128:
+        # the 256 x 256 tile on sixteen waves (large prefills) runs the same fp32 chain per output as the 128-tile: bit-identical
+        from dualhyp_amd import _lib
+        base = {"plain": ops.linear_fp8(xq, xs, wqd, wsd), "resid": ops.linear_fp8(xq, xs, wqd, wsd, resid=dv(r)),
+                "swiglu": ops.linear_fp8(xq, xs, wqd, wsd, epilogue=ops.EPI_SWIGLU, w2q=w2qd, w2_scale=w2sd),
+                "adapter": ops.linear_fp8(xq, xs, wqd, wsd, epilogue=ops.EPI_ADAPTER, scale=dv(sc), bias=dv(bi))}
+        _lib.load().dh_set_tuning(19, 256)
+        try:
+            big = {"plain": ops.linear_fp8(xq, xs, wqd, wsd), "resid": ops.linear_fp8(xq, xs, wqd, wsd, resid=dv(r)),
+                   "swiglu": ops.linear_fp8(xq, xs, wqd, wsd, epilogue=ops.EPI_SWIGLU, w2q=w2qd, w2_scale=w2sd),
+                   "adapter": ops.linear_fp8(xq, xs, wqd, wsd, epilogue=ops.EPI_ADAPTER, scale=dv(sc), bias=dv(bi))}
+        finally:
+            _lib.load().dh_set_tuning(19, 0)
+        for k in base:
+            assert torch.equal(base[k], big[k]), f"256-tile fp8 GEMM differs from the 128-tile ({k}, M={M} N={N} K={K})"
     if M <= 128:
         # a row's bits do not depend on how many rows ride along, inside either kernel (1 row vs all M, across the
         # 32- and 64-row group boundaries of the streaming kernel)
