@@ -23,6 +23,10 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 
 int g_fp8_tile = 0;   // dh_set_tuning key 19: 0 = by grid size, 128 / 256 = forced tile edge of the tiled fp8 GEMM
+// dh_set_tuning key 20: m-tiles per band of the tiled fp8 GEMM's tile walk (1 = row-major, 0 = by kernel).  tools/sweep_fp8_tiles.py
+// at M = 49152, PFLOP/s by band 1 / 2 / 4 / 8 — 256-tile: qkv 1.99 / 2.04 / 2.10 / 1.95, proj 1.71 / 1.64 / 1.80 / 1.56, SwiGLU 2.15 /
+// 2.27 / 2.07 / 2.07, mlp 2.08 / 2.06 / 2.16 / 2.01; 128-tile: qkv 1.31 / 1.49 / 1.68 / 1.75, SwiGLU 1.63 / 1.80 / 1.81 / 1.59
+int g_fp8_gm = 0;
 
 namespace {
 
@@ -186,6 +190,7 @@ struct Fp8Args {
     const bf16_t* resid;   // [M, N] or null
     int M, N, K;
     int nb_n, nb_m;
+    int gm;                // tiled kernel: m-tiles per band of the tile walk (0 / 1 = row-major)
 };
 
 constexpr int BT = 128;                 // block tile edge
@@ -233,7 +238,17 @@ __global__ __launch_bounds__(WG * WG * 64, WG == 2 ? 2 : 1) void gemm_fp8_kernel
         const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int tm = tile / a.nb_n, tn = tile % a.nb_n;
+    // tiles are walked in bands of gm m-tiles, m fastest (as gemm256.hip): the ~32 blocks an XCD runs at a time form a
+    // gm x (32 / gm) rectangle that shares gm x-tile and 32 / gm W-tile streams through its L2 instead of 1 + 32 — a 256-tile
+    // stages 2 MiB per tile, 9.4 GB per QKV launch if nothing is shared
+    int tm, tn;
+    if (a.gm > 1) {
+        const int band = tile / (a.gm * a.nb_n), within = tile - band * (a.gm * a.nb_n);
+        const int rows = min(a.gm, a.nb_m - band * a.gm);
+        tm = band * a.gm + within % rows; tn = within / rows;
+    } else {
+        tm = tile / a.nb_n; tn = tile % a.nb_n;
+    }
     const int m0 = tm * BTW;
     const int n0 = (EPI == DH_EPI_SWIGLU) ? tn * (WG * 32) : tn * BTW;
 
@@ -547,8 +562,10 @@ int launch_tiled(Fp8Args a, hipStream_t s) {
     // 256 x 256 tiles on sixteen waves when they still give every CU two tiles to walk (prefill); the same fp32 chain per
     // output as the 128-tile (one accumulator, k ascending in steps of 128), so rows stay bit-identical across the choice
     const int nbm = cdiv(a.M, 256), nbn = EPI == DH_EPI_SWIGLU ? cdiv(a.N, 128) : cdiv(a.N, 256);
+    a.gm = g_fp8_gm ? g_fp8_gm : 4;
     if (g_fp8_tile ? g_fp8_tile == 256 : nbm * nbn >= 512) {
         a.nb_m = nbm; a.nb_n = nbn;
+        if (!g_fp8_gm && EPI == DH_EPI_SWIGLU) a.gm = 2;
         return a.resid ? launch_tiled_n<EPI, true, 2, 4>(a, s) : launch_tiled_n<EPI, false, 2, 4>(a, s);
     }
     // as gemm.hip: grids smaller than the chip walk K alone -> 4 stages, one block per CU; else 2 stages, two blocks
@@ -603,7 +620,7 @@ extern "C" int dh_linear_fp8_f32(const uint8_t* xq, const float* x_scale, const 
     DH_CHECK(xq && x_scale && wq && w_scale && y32, "dh_linear_fp8_f32: null operand");
     DH_CHECK(M >= 1 && M <= FP8_STREAM_MAX_ROWS && N > 0 && K > 0 && K % 128 == 0, "dh_linear_fp8_f32: needs 1 <= M <= %d and K %% 128 == 0 (M=%d K=%d)",
              FP8_STREAM_MAX_ROWS, M, K);
-    Fp8Args a{xq, wq, nullptr, reinterpret_cast<bf16_t*>(y32), x_scale, w_scale, nullptr, nullptr, nullptr, nullptr, M, N, K, 0, 0};
+    Fp8Args a{xq, wq, nullptr, reinterpret_cast<bf16_t*>(y32), x_scale, w_scale, nullptr, nullptr, nullptr, nullptr, M, N, K, 0, 0, 1};
     dim3 grid(cdiv(N, ROWS)), block(512);
     hipStream_t s = (hipStream_t)stream;
     // row groups as launch_skinny: the same kernel (and bits) as dh_linear_fp8's streaming form, fp32 store
@@ -636,7 +653,7 @@ extern "C" int dh_linear_fp8_ex(const uint8_t* xq, const float* x_scale, const u
     DH_CHECK(epilogue != DH_EPI_SWIGLU || (w2q && w2_scale && !resid), "dh_linear_fp8: SWIGLU needs w2/w2_scale and takes no residual");
     DH_CHECK(epilogue != DH_EPI_ADAPTER || (vec_a && vec_b), "dh_linear_fp8: ADAPTER needs scale/bias vectors");
     if (M == 0) return 0;
-    Fp8Args a{xq, wq, w2q, y, x_scale, w_scale, w2_scale, vec_a, vec_b, resid, M, N, K, 0, 0};
+    Fp8Args a{xq, wq, w2q, y, x_scale, w_scale, w2_scale, vec_a, vec_b, resid, M, N, K, 0, 0, 1};
     hipStream_t s = (hipStream_t)stream;
     if (kernel == 2 || (kernel == 0 && M <= FP8_STREAM_MAX_ROWS)) {      // weight streaming: the decode step of up to four 32-row batches
         switch (epilogue) {

@@ -28,9 +28,11 @@ for name, N, K, epi in (("qkv", 6144, d, ops.EPI_PLAIN), ("proj+resid", d, d, op
     out = {}
     for tile in (128, 256):
         lib.dh_set_tuning(19, tile)
-        fn = lambda: ops.linear_fp8(x, xs, w, ws, epilogue=epi, w2q=w2, w2_scale=ws if w2 is not None else None, resid=resid, kernel=1)
-        out[tile] = fn()
-        t = timeit(fn)
-        print(f"{name:11s} M={M} N={N} K={K}  tile {tile}: {t:8.1f} us  {flop / t / 1e9:6.3f} PFLOP/s", flush=True)
-    lib.dh_set_tuning(19, 0)
+        for gm in (1, 2, 4, 8):                  # m-tiles per band of the tile walk
+            lib.dh_set_tuning(20, gm)
+            fn = lambda: ops.linear_fp8(x, xs, w, ws, epilogue=epi, w2q=w2, w2_scale=ws if w2 is not None else None, resid=resid, kernel=1)
+            out[tile] = fn()
+            t = timeit(fn)
+            print(f"{name:11s} M={M} N={N} K={K}  tile {tile} band {gm}: {t:8.1f} us  {flop / t / 1e9:6.3f} PFLOP/s", flush=True)
+    lib.dh_set_tuning(19, 0); lib.dh_set_tuning(20, 0)
     print(f"{name:11s} bit-identical across tile sizes: {torch.equal(out[128], out[256])}", flush=True)
