@@ -297,7 +297,9 @@ def main() -> None:
             "roofline": {"bound": "mfma", "kernel": wl["kernel"],
                          "achieved": achieved, "peak": wl["peak"], "unit": "TFLOP/s",
                          "frac": achieved / wl["peak"], "traffic": traffic,
-                         "traffic_source": "profiles/r02_pmc_gemm_v2.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_gemm.py, mean bytes per launch; L2-miss traffic on the fabric, Infinity-Cache hits included)",
+                         "traffic_source": ("profiles/r02_pmc_gemm_v2.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_gemm.py, mean bytes per "
+                                            "launch; L2-miss traffic on the fabric, Infinity-Cache hits included)") if traffic is not None else
+                                           "not collected for this workload (PMC passes exist for the headline config's GEMMs only)",
                          "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
                          "prefill_attention_ms_per_step": attn_ms / max(a.steps, 1)},
         }
