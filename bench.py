@@ -136,7 +136,7 @@ def main() -> None:
                          "number of 256-tile rounds on 256 CUs (the qkv GEMM is 2.5 rounds at one batch)")
     ap.add_argument("--ragged", action="store_true",
                     help="SURVEY §8d ragged variant: prompt lengths uniform in [384, 640] instead of 512 (not the headline config)")
-    ap.add_argument("--pack", type=int, default=8,
+    ap.add_argument("--pack", type=int, default=32,
                     help="--config finetune-tinyllama: micro-batches of the accumulation window per packed forward/backward launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap-probe", action="store_true")

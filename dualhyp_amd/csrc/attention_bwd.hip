@@ -98,31 +98,64 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(
     const int n_qt = (len + 31) / 32;
     const bf16_t* qTh = qT + (size_t)head * HS * n_pad + ps;
     const bf16_t* doTh = doT + (size_t)head * HS * n_pad + ps;
-    for (int qt = kt; qt < n_qt; ++qt) {
-        const int q0 = qt * 32;
-        int qrow = q0 + lr;
+    // Software pipeline (round 3): a wave walks its query tiles alone (nothing is shared between the heads of a block), so
+    // every global load it waits for is exposed.  The row fragments of q / dO and the row terms (lse, D) of tile qt+1 are
+    // requested at the top of iteration qt, the transposed pieces of tile qt before its first MFMA: by the time they are
+    // needed one whole phase of MFMAs and exps has passed.  lse / D travel as ONE value per lane (row q0 + lane % 32) and
+    // reach the accumulator layout's rows through ds_bpermute instead of 16 loads per lane each.
+    constexpr bool PIPE = HS == 64;       // hs 128 doubles every fragment set: the second set of row operands would spill
+    struct RowOps { bf16x8 qf[KS], dof[KS]; float l, d; };
+    auto load_rows = [&](RowOps& R, int qt) __attribute__((always_inline)) {
+        int qrow = qt * 32 + lr;
         qrow = qrow < len ? qrow : len - 1;
         const bf16_t* qp = q + ((size_t)(qs + qrow) * n_head + head) * HS + lh * 8;
         const bf16_t* dop = dout + ((size_t)(qs + qrow) * n_head + head) * HS + lh * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            R.qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+            R.dof[ks] = *reinterpret_cast<const bf16x8*>(dop + ks * 16);
+        }
+        R.l = lse[(size_t)(qs + qrow) * n_head + head];
+        R.d = dsum[(size_t)(qs + qrow) * n_head + head];
+    };
+    RowOps cur, nxt;
+    load_rows(cur, kt);
+    for (int qt = kt; qt < n_qt; ++qt) {
+        const int q0 = qt * 32;
+        // transposed pieces of THIS tile (A operands of the dV / dK products), requested before the S / dP products
+        union TP { bf16x8 v; uint2 h[2]; };
+        TP af[2][DT], bfr[2][DT];
+        auto load_tr = [&](int s2) __attribute__((always_inline)) {
+            const int qo = q0 + 16 * s2 + 4 * lh;        // tokens qo..qo+3 and qo+8..qo+11 (padded copy: in bounds)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const size_t row = (size_t)(dt * 32 + lr) * n_pad;
+                af[s2][dt].h[0] = *reinterpret_cast<const uint2*>(doTh + row + qo);
+                af[s2][dt].h[1] = *reinterpret_cast<const uint2*>(doTh + row + qo + 8);
+                bfr[s2][dt].h[0] = *reinterpret_cast<const uint2*>(qTh + row + qo);
+                bfr[s2][dt].h[1] = *reinterpret_cast<const uint2*>(qTh + row + qo + 8);
+            }
+        };
+        if (PIPE) load_tr(0);
+        if (PIPE && qt + 1 < n_qt) load_rows(nxt, qt + 1);       // wave-uniform
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 qf = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
-            const bf16x8 dof = *reinterpret_cast<const bf16x8*>(dop + ks * 16);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf, kf[ks], s, 0, 0, 0);       // rows q, cols key
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dof, vf[ks], dp, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.qf[ks], kf[ks], s, 0, 0, 0);       // rows q, cols key
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.dof[ks], vf[ks], dp, 0, 0, 0);
         }
+        if (PIPE) load_tr(1);                            // lands under the exps below
         // P and dS in the accumulator layout: row (q) = (r&3) + 8*(r>>2) + 4*lh, col (key) = lr
         const int key_abs = key0 + lr;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int qa = q0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int qrel = (r & 3) + 8 * (r >> 2) + 4 * lh;          // row of the tile: lane qrel (either half) holds its lse / D
+            const int qa = q0 + qrel;
             const bool ok = qa < len && key_abs < len && key_abs <= qa;
-            const int qi = qa < len ? qa : len - 1;
-            const float l = lse[(size_t)(qs + qi) * n_head + head];
-            const float dd = dsum[(size_t)(qs + qi) * n_head + head];
+            const float l = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(qrel << 2, __builtin_bit_cast(int, cur.l)));
+            const float dd = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(qrel << 2, __builtin_bit_cast(int, cur.d)));
             const float p = ok ? __expf(s[r] * scale - l) : 0.f;
             s[r] = p;
             dp[r] = p * (dp[r] - dd);
@@ -135,18 +168,23 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(
                 pf.u[j] = pack2bf(s[8 * s2 + 2 * j], s[8 * s2 + 2 * j + 1]);
                 dsf.u[j] = pack2bf(dp[8 * s2 + 2 * j], dp[8 * s2 + 2 * j + 1]);
             }
-            const int qo = q0 + 16 * s2 + 4 * lh;        // tokens qo..qo+3 and qo+8..qo+11 (padded copy: in bounds)
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                const size_t row = (size_t)(dt * 32 + lr) * n_pad;
-                union { bf16x8 v; uint2 h[2]; } af, bfr;
-                af.h[0] = *reinterpret_cast<const uint2*>(doTh + row + qo);
-                af.h[1] = *reinterpret_cast<const uint2*>(doTh + row + qo + 8);
-                bfr.h[0] = *reinterpret_cast<const uint2*>(qTh + row + qo);
-                bfr.h[1] = *reinterpret_cast<const uint2*>(qTh + row + qo + 8);
-                dvT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.v, pf.v, dvT[dt], 0, 0, 0);    // [d][key]
-                dkT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr.v, dsf.v, dkT[dt], 0, 0, 0);
+                if (!PIPE) {                               // hs 128: one piece pair at a time (8 registers live)
+                    const int qo = q0 + 16 * s2 + 4 * lh;
+                    const size_t row = (size_t)(dt * 32 + lr) * n_pad;
+                    af[s2][dt].h[0] = *reinterpret_cast<const uint2*>(doTh + row + qo);
+                    af[s2][dt].h[1] = *reinterpret_cast<const uint2*>(doTh + row + qo + 8);
+                    bfr[s2][dt].h[0] = *reinterpret_cast<const uint2*>(qTh + row + qo);
+                    bfr[s2][dt].h[1] = *reinterpret_cast<const uint2*>(qTh + row + qo + 8);
+                }
+                dvT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s2][dt].v, pf.v, dvT[dt], 0, 0, 0);    // [d][key]
+                dkT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[s2][dt].v, dsf.v, dkT[dt], 0, 0, 0);
             }
+        }
+        if (qt + 1 < n_qt) {
+            if (PIPE) cur = nxt;
+            else load_rows(cur, qt + 1);
         }
     }
     // ---- sum the heads of the group (LDS), then write dK (scaled) and dV: lane col = key, rows = d.  The waves pass
