@@ -155,8 +155,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
                 if (a.lora_b != nullptr) {
                     f32x4 lacc = {0.f, 0.f, 0.f, 0.f};
                     lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lbv[i], xfv[i >> 1], lacc, 0, 0, 0);
+                    // lora_scale == 1 (alpha == r, the reference harnesses' setting): bf16(bf16(l) * 1) is bf16(l) — a wave-uniform
+                    // branch drops a multiply and a rounding per element of this VALU-bound epilogue, same bits
+                    float lt[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) ov[i][e] = rbf(ov[i][e] + rbf(rbf(lacc[e]) * a.lora_scale));
+                    for (int e = 0; e < 4; ++e) lt[e] = rbf(lacc[e]);
+                    if (a.lora_scale != 1.f) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) lt[e] = rbf(lt[e] * a.lora_scale);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ov[i][e] = rbf(ov[i][e] + lt[e]);
                 }
             }
             {
@@ -249,8 +258,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
                 if (EPI == DH_EPI_LORA) {
                     f32x4 lacc = {0.f, 0.f, 0.f, 0.f};
                     lacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lbv[LORA ? i : 0], xfv[LORA ? i >> 1 : 0], lacc, 0, 0, 0);
+                    float lt[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = rbf(o[e] + rbf(rbf(lacc[e]) * a.lora_scale));
+                    for (int e = 0; e < 4; ++e) lt[e] = rbf(lacc[e]);
+                    if (a.lora_scale != 1.f) {           // wave-uniform; see the QKV epilogue
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) lt[e] = rbf(lt[e] * a.lora_scale);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = rbf(o[e] + lt[e]);
                 }
                 if (EPI == DH_EPI_ADAPTER && ok) {
                     const uint2 sc = *reinterpret_cast<const uint2*>(a.vec_a + n);

@@ -45,6 +45,7 @@ struct DtArgs {
     const bf16_t* resid;
     int M, N, K, n_main, seg;   // seg: k-steps per chain segment (even)
     int split_kt;               // MODE 4: 64-wide stages per block (two segments); else 0
+    int wt;                     // MODE 4: write-through (sc1) stores of the pair sums
 };
 
 // NSTAGE 4: one block per CU, 3 stages in flight; NSTAGE 2: two blocks per CU.  WN 2: 4 waves, 128 W rows per block;
@@ -224,7 +225,12 @@ __global__ __launch_bounds__(WN * 128) void gemm_dt_kernel(DtArgs a) {
                 if (n >= a.N) continue;
                 if (MODE == 0 || MODE == 4) {
                     float* yo = (float*)a.y + (MODE == 4 ? (size_t)ky * a.M * a.N : 0);
-                    *reinterpret_cast<f32x4*>(yo + (size_t)m * a.N + n) = tot[i][j];
+                    float* dst = yo + (size_t)m * a.N + n;
+                    // the partial sums are read next by OTHER blocks, 7 of 8 of them on another XCD (whose L2 is not coherent
+                    // with this one): write them through (sc1) so they leave this L2 while the kernel runs instead of as a
+                    // 20-27 MB write-back at the kernel boundary (dh_set_tuning key 21: 0 = plain stores)
+                    if (MODE == 4 && a.wt) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(tot[i][j]) : "memory");
+                    else *reinterpret_cast<f32x4*>(dst) = tot[i][j];
                     continue;
                 }
                 float o[4];
@@ -285,7 +291,7 @@ int g_chain_min_rows = 1280;   // partial-sum GEMMs from this many rows on (dh_s
 // x·[w; w_ext]^T summed over the K-slices of `kps` k-steps in slice order: fp32 [M][n_main + n_ext]
 int dh_chain_tiled(const bf16_t* x, const bf16_t* w, const bf16_t* w_ext, float* y32, int M, int n_main, int n_ext, int K,
                    int kps, hipStream_t s) {
-    DtArgs a{x, w, w_ext ? w_ext : w, y32, nullptr, nullptr, nullptr, M, n_main + n_ext, K, n_main, kps, 0};
+    DtArgs a{x, w, w_ext ? w_ext : w, y32, nullptr, nullptr, nullptr, M, n_main + n_ext, K, n_main, kps, 0, 0};
     return launch_dt<0>(a, s);
 }
 
@@ -293,10 +299,11 @@ int dh_chain_tiled(const bf16_t* x, const bf16_t* w, const bf16_t* w_ext, float*
 // block per (tile, slice pair).  Tile shape by grid size: 128 x 256 on 8 waves (3 stages of 48 KiB) when that still gives
 // every CU a block, else 128 x 128 on 4 waves (dh_set_tuning key 17: 0 auto, 2 / 4 = waves along n).
 int g_pairs_wn = 0;
+int g_pairs_wt = 1;
 int dh_pairs_tiled(const bf16_t* x, const bf16_t* w, const bf16_t* w_ext, float* y32, int M, int n_main, int n_ext, int K,
                    int kps, hipStream_t s) {
     const int N = n_main + n_ext, nslices = cdiv(K / 32, kps), ny = (nslices + 1) / 2;
-    DtArgs a{x, w, w_ext ? w_ext : w, y32, nullptr, nullptr, nullptr, M, N, K, n_main, kps, kps};   // kps k-steps = kps/2 stages per slice, two slices per block
+    DtArgs a{x, w, w_ext ? w_ext : w, y32, nullptr, nullptr, nullptr, M, N, K, n_main, kps, kps, g_pairs_wt};   // kps k-steps = kps/2 stages per slice, two slices per block
     const int m_tiles = cdiv(M, TB);
     const int wide_blocks = m_tiles * cdiv(N, 256) * ny;
     const bool wide = g_pairs_wn ? g_pairs_wn == 4 : wide_blocks >= 160;   // 640 rows: qkv' 220, proj' 180, mlp' 240 blocks of 128 x 256
@@ -311,7 +318,7 @@ bool dh_linear_dt_ok(const GemmArgs& a, int epilogue, int seg) {
 }
 
 int dh_linear_dt(const GemmArgs& g, int epilogue, int seg, hipStream_t s) {
-    DtArgs a{g.x, g.w, g.w2, g.y, g.vec_a, g.vec_b, g.resid, g.M, g.N, g.K, g.N, seg, 0};
+    DtArgs a{g.x, g.w, g.w2, g.y, g.vec_a, g.vec_b, g.resid, g.M, g.N, g.K, g.N, seg, 0, 0};
     switch (epilogue) {
         case DH_EPI_SWIGLU: return launch_dt<1>(a, s);
         case DH_EPI_ADAPTER: return launch_dt<2>(a, s);
