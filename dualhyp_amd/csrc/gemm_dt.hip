@@ -299,7 +299,7 @@ int dh_chain_tiled(const bf16_t* x, const bf16_t* w, const bf16_t* w_ext, float*
 // block per (tile, slice pair).  Tile shape by grid size: 128 x 256 on 8 waves (3 stages of 48 KiB) when that still gives
 // every CU a block, else 128 x 128 on 4 waves (dh_set_tuning key 17: 0 auto, 2 / 4 = waves along n).
 int g_pairs_wn = 0;
-int g_pairs_wt = 1;
+int g_pairs_wt = 0;   // write-through (sc1) stores of the pair sums: measured neutral (decode 4.74-4.77 ms per token either way), off
 int dh_pairs_tiled(const bf16_t* x, const bf16_t* w, const bf16_t* w_ext, float* y32, int M, int n_main, int n_ext, int K,
                    int kps, hipStream_t s) {
     const int N = n_main + n_ext, nslices = cdiv(K / 32, kps), ny = (nslices + 1) / 2;
