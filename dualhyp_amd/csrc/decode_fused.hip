@@ -15,10 +15,15 @@ constexpr int DCOLS = 16;   // padded head columns of the attention partials
 constexpr int MAXP = 16;    // most K-slices a partial-sum GEMM emits
 
 // --------------------------------------------------------------------------- attention (decode)
-// grid (n_seq * n_groups), 512 threads.  qkv32: [n_part][n_seq][ldq] fp32, ldq = qkv_dim + n_ext;
+// grid (n_seq * n_groups), NW waves (hs 64: 16, hs 128: 8).  qkv32: [n_part][n_seq][ldq] fp32, ldq = qkv_dim + n_ext;
 // columns [qkv_dim, qkv_dim+48) hold x·A^T of the q/k/v LoRA (when lora_b != null).
-template <int HS, int PMAX>
-__global__ __launch_bounds__(512, HS == 64 ? 4 : 2) void attn_decode_fused_kernel(
+// NW waves share the key tiles of one (sequence, group).  Round 3: SIXTEEN waves at hs 64 — at the benchmark's ~544 cached keys
+// (17 tiles) every tile is then requested before the LoRA / rope prologue and no wave walks a second or third tile behind an
+// exposed HBM round trip (with 8 waves the loop issued a tile's loads only after computing the previous one; the 640-row step
+// spent 85 us per layer here, 4.5 TB/s).  The tile -> wave deal and the combine order are a property of the head size, never
+// of the row count, so batch invariance is untouched; hs 128 keeps 8 waves (its tile and accumulators need 256 VGPRs).
+template <int HS, int PMAX, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 16 ? 1 : (HS == 64 ? 4 : 2)) void attn_decode_fused_kernel(
     const float* __restrict__ qkv32, int n_part, int pairs, int n_seq, int ldq, int qkv_dim,
     const bf16_t* __restrict__ lora_b, float lora_scale, int split0, int split1,
     const bf16_t* __restrict__ cos, const bf16_t* __restrict__ sin, const int32_t* __restrict__ seq_slot,
@@ -38,9 +43,10 @@ __global__ __launch_bounds__(512, HS == 64 ? 4 : 2) void attn_decode_fused_kerne
     float* sVn = sKn + HS;                                              // [HS] new value
     float* sXa = sVn + HS;                                              // [48] bf16(x·A^T)
     float* sSn = sXa + 48;                                              // [16] score of the new key
-    float* sPm = sSn + 16;                                              // [8][DCOLS] running max
-    float* sPl = sPm + 8 * DCOLS;                                       // [8][DCOLS] running sum
-    float* sPo = sPl + 8 * DCOLS;                                       // [8][HS][DCOLS] partial O^T
+    float* sPm = sSn + 16;                                              // [NW][DCOLS] running max
+    float* sPl = sPm + NW * DCOLS;                                      // [NW][DCOLS] running sum
+    float* sPo = sPl + NW * DCOLS;                                      // [NW][HS][DCOLS] partial O^T
+    constexpr int NT_ = NW * 64;                                        // threads
 
     // ---- request the K / V^T operands of this wave's first PF tiles before anything else: they do
     // not depend on the new token, and their HBM latency hides under the LoRA/rope phase
@@ -64,7 +70,7 @@ __global__ __launch_bounds__(512, HS == 64 ? 4 : 2) void attn_decode_fused_kerne
     };
 #pragma unroll
     for (int p = 0; p < PF; ++p)
-        if (wave + 8 * p < n_tiles) load_tile(tl[p], wave + 8 * p);
+        if (wave + NW * p < n_tiles) load_tile(tl[p], wave + NW * p);
 
     const float* row0 = qkv32 + (size_t)seq * ldq;
     const size_t pstride = (size_t)n_seq * ldq;
@@ -87,7 +93,7 @@ __global__ __launch_bounds__(512, HS == 64 ? 4 : 2) void attn_decode_fused_kerne
         return s;
     };
     if (lora_b != nullptr && tid < 48) sXa[tid] = rbf(psum(qkv_dim + tid));
-    for (int i = tid; i < 16 * HS; i += 512) sQ[i] = 0;               // zero padding rows of Q
+    for (int i = tid; i < 16 * HS; i += NT_) sQ[i] = 0;               // zero padding rows of Q
     __syncthreads();
 
     // bf16 value of fused-qkv column c: bf16(bf16(x·W^T) + bf16(bf16(xa·B^T)*s))
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(512, HS == 64 ? 4 : 2) void attn_decode_fused_kerne
     bf16_t* kdst = k_cache + ((size_t)slot * n_groups + g) * s_max * HS;
     bf16_t* vdst = vT_cache + ((size_t)slot * n_groups + g) * HS * s_max;
     const int n_rope = (q_per_kv + 1) * HALF;
-    for (int it = tid; it < n_rope + HS; it += 512) {
+    for (int it = tid; it < n_rope + HS; it += NT_) {
         if (it < n_rope) {
             const int j = it / HALF, i = it % HALF;
             const float x1 = finish(gbase + j * HS + i), x2 = finish(gbase + j * HS + HALF + i);
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(512, HS == 64 ? 4 : 2) void attn_decode_fused_kerne
 
     // score of the new key against each head (it is merged at the combine, so nobody has to
     // read this block's own cache write back)
-    for (int h = wave; h < q_per_kv; h += 8) {
+    for (int h = wave; h < q_per_kv; h += NW) {
         float p = 0.f;
         for (int e = lane; e < HS; e += 64) p += bf2f(sQ[h * HS + e]) * sKn[e];
         p = wave_sum(p);
@@ -206,13 +212,13 @@ __global__ __launch_bounds__(512, HS == 64 ? 4 : 2) void attn_decode_fused_kerne
             }
         }
     };
-    for (int base = wave; base < n_tiles; base += 8 * PF) {
+    for (int base = wave; base < n_tiles; base += NW * PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p)
-            if (base + 8 * p < n_tiles) compute_tile(tl[p], base + 8 * p);
+            if (base + NW * p < n_tiles) compute_tile(tl[p], base + NW * p);
 #pragma unroll
         for (int p = 0; p < PF; ++p)
-            if (base + 8 * (PF + p) < n_tiles) load_tile(tl[p], base + 8 * (PF + p));
+            if (base + NW * (PF + p) < n_tiles) load_tile(tl[p], base + NW * (PF + p));
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     if (lr < q_per_kv) {
@@ -229,17 +235,17 @@ __global__ __launch_bounds__(512, HS == 64 ? 4 : 2) void attn_decode_fused_kerne
             }
     }
     __syncthreads();
-    // ---- combine the 8 wave partials and the new key
-    for (int it = tid; it < q_per_kv * HS; it += 512) {
+    // ---- combine the NW wave partials and the new key
+    for (int it = tid; it < q_per_kv * HS; it += NT_) {
         const int h = it / HS, d = it % HS;
         const float sn = sSn[h];
         float M = sn;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) M = fmaxf(M, sPm[w * DCOLS + h]);
+        for (int w = 0; w < NW; ++w) M = fmaxf(M, sPm[w * DCOLS + h]);
         const float pn = __expf(sn - M);
         float L = pn, O = rbf(pn) * sVn[d];
 #pragma unroll
-        for (int w = 0; w < 8; ++w) {
+        for (int w = 0; w < NW; ++w) {
             const float mw = sPm[w * DCOLS + h];
             const float f = (mw == -INFINITY) ? 0.f : __expf(mw - M);
             L += sPl[w * DCOLS + h] * f;
@@ -250,8 +256,11 @@ __global__ __launch_bounds__(512, HS == 64 ? 4 : 2) void attn_decode_fused_kerne
 }
 
 template <int HS>
+constexpr int attn_fused_waves() { return HS == 64 ? 16 : 8; }
+template <int HS>
 constexpr size_t attn_fused_lds() {
-    return 16 * HS * 2 + (HS + HS + 48 + 16 + 8 * DCOLS + 8 * DCOLS + 8 * HS * DCOLS) * sizeof(float);
+    constexpr int NW = attn_fused_waves<HS>();
+    return 16 * HS * 2 + (HS + HS + 48 + 16 + NW * DCOLS + NW * DCOLS + NW * HS * DCOLS) * sizeof(float);
 }
 
 // --------------------------------------------------------------------------- finish + norm
@@ -390,19 +399,22 @@ extern "C" int dh_attn_decode_fused_bf16(const float* qkv32, int n_part, int pai
     if (n_seq <= 0) return 0;
     const float scale = 1.0f / sqrtf((float)hs);
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(n_seq * n_groups), block(512);
+    dim3 grid(n_seq * n_groups);
 #define ATT_LAUNCH(HSV, PM)                                                                                           \
-    hipLaunchKernelGGL((attn_decode_fused_kernel<HSV, PM>), grid, block, attn_fused_lds<HSV>(), s, qkv32, n_part, pairs, n_seq,  \
+    hipLaunchKernelGGL((attn_decode_fused_kernel<HSV, PM, attn_fused_waves<HSV>()>), grid, dim3(64 * attn_fused_waves<HSV>()), attn_fused_lds<HSV>(), s, qkv32, n_part, pairs, n_seq,  \
                        qkv_dim + n_ext, qkv_dim, lora_b, lora_scale, split0, split1, cos, sin, seq_slot, kv_len, k_cache,  \
                        vT_cache, y, n_head, n_groups, s_max, scale)
     if (hs == 64) {
+        DH_MAX_LDS_ONCE((attn_decode_fused_kernel<64, 2, 16>), attn_fused_lds<64>());
+        DH_MAX_LDS_ONCE((attn_decode_fused_kernel<64, 8, 16>), attn_fused_lds<64>());
+        DH_MAX_LDS_ONCE((attn_decode_fused_kernel<64, 16, 16>), attn_fused_lds<64>());
         if (n_part <= 2) ATT_LAUNCH(64, 2);
         else if (n_part <= 8) ATT_LAUNCH(64, 8);
         else ATT_LAUNCH(64, 16);
     } else {
-        DH_MAX_LDS_ONCE((attn_decode_fused_kernel<128, 2>), attn_fused_lds<128>());
-        DH_MAX_LDS_ONCE((attn_decode_fused_kernel<128, 8>), attn_fused_lds<128>());
-        DH_MAX_LDS_ONCE((attn_decode_fused_kernel<128, 16>), attn_fused_lds<128>());
+        DH_MAX_LDS_ONCE((attn_decode_fused_kernel<128, 2, 8>), attn_fused_lds<128>());
+        DH_MAX_LDS_ONCE((attn_decode_fused_kernel<128, 8, 8>), attn_fused_lds<128>());
+        DH_MAX_LDS_ONCE((attn_decode_fused_kernel<128, 16, 8>), attn_fused_lds<128>());
         if (n_part <= 2) ATT_LAUNCH(128, 2);
         else if (n_part <= 8) ATT_LAUNCH(128, 8);
         else ATT_LAUNCH(128, 16);
