@@ -23,7 +23,7 @@ constexpr int MAXP = 16;    // most K-slices a partial-sum GEMM emits
 // spent 85 us per layer here, 4.5 TB/s).  The tile -> wave deal and the combine order are a property of the head size, never
 // of the row count, so batch invariance is untouched; hs 128 keeps 8 waves (its tile and accumulators need 256 VGPRs).
 template <int HS, int PMAX, int NW>
-__global__ __launch_bounds__(NW * 64, NW == 16 ? 1 : (HS == 64 ? 4 : 2)) void attn_decode_fused_kernel(
+__global__ __launch_bounds__(NW * 64, NW == 16 ? 1 : (NW == 6 ? 3 : (HS == 64 ? 4 : 2))) void attn_decode_fused_kernel(
     const float* __restrict__ qkv32, int n_part, int pairs, int n_seq, int ldq, int qkv_dim,
     const bf16_t* __restrict__ lora_b, float lora_scale, int split0, int split1,
     const bf16_t* __restrict__ cos, const bf16_t* __restrict__ sin, const int32_t* __restrict__ seq_slot,
@@ -50,7 +50,10 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 1 : (HS == 64 ? 4 : 2)) void at
 
     // ---- request the K / V^T operands of this wave's first PF tiles before anything else: they do
     // not depend on the new token, and their HBM latency hides under the LoRA/rope phase
-    constexpr int PF = 1;   // one tile of operands in flight per wave: 128 VGPRs, two blocks per CU (hs 64)
+    // tiles of operands in flight per wave.  8 waves: one (128 VGPRs, two blocks per CU at hs 64); SIX waves (round 3, hs 64): two —
+    // three waves per SIMD leave 168 VGPRs, and at ~544 keys (17 tiles = 3 per wave) the third tile's loads are issued right
+    // after the first tile is consumed and land under the second: no tile waits for an exposed HBM round trip
+    constexpr int PF = NW == 6 ? 2 : 1;
     struct VF { bf16x8 v; };
     struct Tile { bf16x8 kf[KS]; VF vf[DT][2]; };
     Tile tl[PF];
@@ -214,11 +217,10 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 1 : (HS == 64 ? 4 : 2)) void at
     };
     for (int base = wave; base < n_tiles; base += NW * PF) {
 #pragma unroll
-        for (int p = 0; p < PF; ++p)
+        for (int p = 0; p < PF; ++p) {
             if (base + NW * p < n_tiles) compute_tile(tl[p], base + NW * p);
-#pragma unroll
-        for (int p = 0; p < PF; ++p)
-            if (base + NW * (PF + p) < n_tiles) load_tile(tl[p], base + NW * (PF + p));
+            if (base + NW * (PF + p) < n_tiles) load_tile(tl[p], base + NW * (PF + p));    // its set is free again
+        }
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     if (lr < q_per_kv) {
@@ -255,8 +257,11 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 1 : (HS == 64 ? 4 : 2)) void at
     }
 }
 
+#ifndef DH_ATTN_WAVES64
+#define DH_ATTN_WAVES64 8     // A/B builds: 6 (two tiles in flight per wave) and 16 (one block per CU: measured 5.68 vs 4.74 ms per 640-row step)
+#endif
 template <int HS>
-constexpr int attn_fused_waves() { return HS == 64 ? 16 : 8; }
+constexpr int attn_fused_waves() { return HS == 64 ? DH_ATTN_WAVES64 : 8; }
 template <int HS>
 constexpr size_t attn_fused_lds() {
     constexpr int NW = attn_fused_waves<HS>();
@@ -405,9 +410,9 @@ extern "C" int dh_attn_decode_fused_bf16(const float* qkv32, int n_part, int pai
                        qkv_dim + n_ext, qkv_dim, lora_b, lora_scale, split0, split1, cos, sin, seq_slot, kv_len, k_cache,  \
                        vT_cache, y, n_head, n_groups, s_max, scale)
     if (hs == 64) {
-        DH_MAX_LDS_ONCE((attn_decode_fused_kernel<64, 2, 16>), attn_fused_lds<64>());
-        DH_MAX_LDS_ONCE((attn_decode_fused_kernel<64, 8, 16>), attn_fused_lds<64>());
-        DH_MAX_LDS_ONCE((attn_decode_fused_kernel<64, 16, 16>), attn_fused_lds<64>());
+        DH_MAX_LDS_ONCE((attn_decode_fused_kernel<64, 2, attn_fused_waves<64>()>), attn_fused_lds<64>());
+        DH_MAX_LDS_ONCE((attn_decode_fused_kernel<64, 8, attn_fused_waves<64>()>), attn_fused_lds<64>());
+        DH_MAX_LDS_ONCE((attn_decode_fused_kernel<64, 16, attn_fused_waves<64>()>), attn_fused_lds<64>());
         if (n_part <= 2) ATT_LAUNCH(64, 2);
         else if (n_part <= 8) ATT_LAUNCH(64, 8);
         else ATT_LAUNCH(64, 16);
