@@ -183,3 +183,39 @@ def test_finetune_bench_two_rank_rehearsal():
     record_parity("bench_finetune.two_rank_rehearsal", mean_loss_1rank=one["mean_loss_last_step"], mean_loss_2ranks=two["mean_loss_last_step"],
                   utt_per_s_1rank=one["value"], utt_per_s_2ranks_one_gpu=two["value"])
     assert abs(one["mean_loss_last_step"] - two["mean_loss_last_step"]) <= 2e-3 * abs(one["mean_loss_last_step"])
+
+
+def test_relprompt_finetune_harness_trains_the_classifiers(tmp_path):
+    """`python -m dualhyp_amd.finetune --prompts_format RelPrompt` (finetune/relprompt.py's flags): the RelPrompt decoder with its
+    three reliability tokens, the two NoiseMaskClassifiers trained in the second AdamW group on encoder features read from
+    --enc_features_dir (the encoders themselves are upstream of this path), targets = the chunk labels of the items' corruption
+    fields; the checkpoint carries trained classifier weights and the grown embedding."""
+    items = merged_items(4)
+    (tmp_path / "train.json").write_text(json.dumps(items))
+    ckpt_dir = tmp_path / "checkpoints" / "parity-harness"
+    ckpt_dir.mkdir(parents=True)
+    feats = tmp_path / "feats"
+    feats.mkdir()
+    g = torch.Generator().manual_seed(0)
+    for it in items:       # 2 s of audio at 50 fps / video at 25 fps: five 0.4-s chunks each
+        torch.save({"audio": torch.randn(100, 1280, generator=g), "visual": torch.randn(50, 1024, generator=g)}, feats / f"{it['Uid']}.pt")
+    run = tmp_path / "runs" / "rp"
+    cmd = [sys.executable, "-m", "dualhyp_amd.finetune", "--train_path", str(tmp_path / "train.json"), "--exp_name", "rp",
+           "--llm_checkpoint", str(ckpt_dir), "--prompts_format", "RelPrompt", "--tokenizer", "byte", "--random_init", "--batch_size", "2",
+           "--micro_batch_size", "1", "--lr", "1e-3", "--classifier_lr", "5e-3", "--mask_loss_weight", "0.02", "--num_epochs", "1",
+           "--enc_features_dir", str(feats), "--out_dir", str(run)]
+    out = subprocess.run(cmd, cwd=tmp_path, env=_env(), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    ck = torch.load(run / "lit_model_lora_finetuned.pth")["model"]
+    from dualhyp_amd import Config
+    cfg = Config.from_name("parity-harness")
+    assert ck["transformer.wte.weight"].size(0) == cfg.padded_vocab_size + 3           # <<C>> / <<M>> / <<N>> rows
+    for k in ("audio_noise_classifier.conv1.weight", "visual_noise_classifier.classifier.bias"):
+        assert k in ck and ck[k].dtype == torch.float32                                  # fp32 masters, trained
+    assert "optimizer_steps': 2" in (run / "train.log").read_text()
+    # the classifier really moved: a fresh RelGPT with the same seed has other weights
+    import random
+    from dualhyp_amd.relprompt import GPT as RelGPT
+    torch.manual_seed(1337); random.seed(1337)
+    fresh = RelGPT(cfg)
+    assert not torch.equal(fresh.audio_noise_classifier.classifier.bias.detach().float(), ck["audio_noise_classifier.classifier.bias"].float())
