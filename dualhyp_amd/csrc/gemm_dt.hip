@@ -285,7 +285,10 @@ int launch_dt(const DtArgs& a, hipStream_t s) {
 // with the rows: the crossover was near 768 rows in round 1; with round 2's K-sliced kernel it lies between 1024 and 2048.
 int g_dt_min_rows = 129;       // fused-epilogue decode GEMMs from this many rows on (dh_set_tuning key 6); the lm_head (N = 32000) already
                                // from 65: measured SwiGLU 24 (streaming) vs 32 us at 128 rows, 40 vs 32 at 130; lm_head 49 vs 39 at 96 rows
-int g_chain_min_rows = 1280;   // partial-sum GEMMs from this many rows on (dh_set_tuning key 7): the K-sliced kernel wins at 1024 rows
+// the one-launch total of the partial-sum GEMMs from this many rows on (dh_set_tuning key 7).  Round 3: OFF by default (1 << 30) — in the
+// family's pair order the kernel needs a third accumulator set (412 registers: one wave per SIMD, one block per CU) and a 2048-row
+// decode step takes 15.25 ms against 13.55 with the pair-sum kernel (round 2's two-set chain in slice order: 13.0).  Kept for the ABI.
+int g_chain_min_rows = 1 << 30;   //
                                // (8.34 vs 8.53 ms per decode step), this kernel at 2048 (12.9 vs 14.6)
 
 // x·[w; w_ext]^T summed over the K-slices of `kps` k-steps in slice order: fp32 [M][n_main + n_ext]

@@ -259,7 +259,7 @@ def test_linear_partial_wide_rows(dev, M, N, n_ext, K, ks):
             try:
                 chain = ops.linear_chain(x, W, A, ksplit=ks)
             finally:
-                _lib.load().dh_set_tuning(7, 1280)
+                _lib.load().dh_set_tuning(7, 1 << 30)
             assert torch.equal(chain, total), "tiled chain sum differs from the family's combine order of the streamed slices"
         # the consumers: slices (pairs flag) and pair sums give the same bits
         if N == 2048 and n_ext == 0:

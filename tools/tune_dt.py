@@ -18,6 +18,6 @@ for M in (256, 512, 1024, 2048):
         lib.dh_set_tuning(7, 65)
         t = bench(lambda i: ops.linear_chain(x, Wq[i % L], A48[i % L], ksplit=8)); print(f"M={M} qkv' chain stages={st}: {t:6.1f} us")
         t = bench(lambda i: ops.linear_chain(xa, Wm[i % L], None, ksplit=11)); print(f"M={M} mlp' chain stages={st}: {t:6.1f} us")
-        lib.dh_set_tuning(7, 1280)
+        lib.dh_set_tuning(7, 1 << 30)
     t = bench(lambda i: ops.linear_partial(x, Wq[i % L], A48[i % L], ksplit=8)); print(f"M={M} qkv' rows partial: {t:6.1f} us")
     t = bench(lambda i: ops.linear_partial(xa, Wm[i % L], None, ksplit=11)); print(f"M={M} mlp' rows partial: {t:6.1f} us")
