@@ -249,6 +249,27 @@ def test_train_micro_step_tinyllama_shape(golden, tag, dtype, autocast):
 
 
 @SLOW
+@pytest.mark.parametrize("tag,dtype,autocast", [("fp32", torch.float32, False), ("mixed", torch.float32, True)])
+def test_train_micro_step_full_depth(golden, tag, dtype, autocast):
+    """BASELINE config 3 at full depth (22 layers, T = 560): the oracle's loss and LoRA gradients against the reference's autograd."""
+    t, meta = golden("train_tinyllama_full")
+    cfg = Config(**meta["config"])
+    sd = {k: v.to(dtype) for k, v in synth_state_dict(cfg, seed=meta["seed"], norm_jitter=meta["norm_jitter"]).items()}
+    loss, grads = O.train_micro_step(cfg, sd, t["input_ids"], t["labels"], grad_accum=meta["grad_accum"], lm_head_chunk_size=128,
+                                     autocast=autocast)
+    assert abs(loss.item() - t[f"{tag}.train_loss"].float().item()) <= (1e-5 if tag == "fp32" else 4e-3)
+    checked = 0
+    for k, g in grads.items():
+        if f"{tag}.grad.{k}" not in t:
+            continue
+        want = t[f"{tag}.grad.{k}"].float()
+        tol = 1e-4 if tag == "fp32" else 2e-2
+        assert (g.float() - want).abs().max().item() <= tol * want.abs().max().item() + 1e-9, (tag, k)
+        checked += 1
+    assert checked == 12       # 3 kept layers x (attn A, B, proj A, B)
+
+
+@SLOW
 def test_full_tinyllama_512(golden):
     """BASELINE config 2's own shape: 22 layers, T = 512, G = 64 (tests/golden/full_tinyllama_512)."""
     t, meta = golden("full_tinyllama_512")
