@@ -19,7 +19,26 @@
 
 namespace {
 
-// src [n_tok, heads, hs] -> dst [heads, hs, n_pad]; token t of sequence i lands at pad_start[i] + (t - start[i])
+// Token-contiguous copies of q / dO / k for the products that take them TRANSPOSED, stored in MFMA-FRAGMENT ORDER (round 3; as the
+// KV cache of the decode path): the A operand of v_mfma_f32_32x32x16_bf16 that multiplies a P / dS accumulator tile needs, per
+// lane (lr = channel % 32, lh), the 8 values of tokens {qo..qo+3, qo+8..qo+11}, qo = 16 s2 + 4 lh, of channel dt*32 + lr.  Padded
+// token p (= pad_start[seq] + position, every sequence starting on a multiple of 32) of channel e of head h lives at
+//     tfrag_off = ((((h * n_pad/32 + p/32) * 2 + s2) * (hs/32) + e/32) * 64 + lh*32 + e%32) * 8 + j
+// with w = p % 32, s2 = w/16, r = w%16, lh = (r%8)/4, j = 4*(r/8) + r%4 — so a wave's fragment is ONE contiguous 1-KiB load
+// (16 B per lane) instead of two 8-byte gathers per lane from 64 different cache lines (the round-2 layout [heads][hs][n_pad]:
+// the texture-address unit, not the matrix pipe, set the pace of both backward kernels).
+template <int HS>
+__device__ __forceinline__ size_t tfrag_off(int h, int n_pad, int p, int e) {
+    const int w = p & 31, s2 = w >> 4, r = w & 15, lh = (r & 7) >> 2, j = ((r >> 3) << 2) + (r & 3);
+    return (((((size_t)h * (n_pad >> 5) + (p >> 5)) * 2 + s2) * (HS / 32) + (e >> 5)) * 64 + lh * 32 + (e & 31)) * 8 + j;
+}
+// 16-byte fragment of (head h, padded tile `tile`, s2, dt) for this lane
+template <int HS>
+__device__ __forceinline__ size_t tfrag_lane(int h, int n_pad, int tile, int s2, int dt, int lane) {
+    return (((((size_t)h * (n_pad >> 5) + tile) * 2 + s2) * (HS / 32) + dt) * 64 + lane) * 8;
+}
+
+// src [n_tok, heads, hs] -> dst in fragment order; token t of sequence i is padded token pad_start[i] + (t - start[i])
 __global__ __launch_bounds__(256) void transpose_pad_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
                                                             const int32_t* __restrict__ tok_seq,
                                                             const int32_t* __restrict__ q_start,
@@ -36,7 +55,8 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const bf16_t* __rest
         const int tl = it & 31, e = it >> 5, t = t0 + tl;
         if (t < n_tok) {
             const int s = tok_seq[t];
-            dst[((size_t)h * hs + e) * n_pad + pad_start[s] + (t - q_start[s])] = tile[tl][e];
+            const int pp = pad_start[s] + (t - q_start[s]);
+            dst[hs == 64 ? tfrag_off<64>(h, n_pad, pp, e) : tfrag_off<128>(h, n_pad, pp, e)] = tile[tl][e];
         }
     }
 }
@@ -96,8 +116,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(
         for (int r = 0; r < 16; ++r) { dkT[dt][r] = 0.f; dvT[dt][r] = 0.f; }
 
     const int n_qt = (len + 31) / 32;
-    const bf16_t* qTh = qT + (size_t)head * HS * n_pad + ps;
-    const bf16_t* doTh = doT + (size_t)head * HS * n_pad + ps;
+    const int tile0 = ps >> 5;           // first padded tile of this sequence
     // Software pipeline (round 3): a wave walks its query tiles alone (nothing is shared between the heads of a block), so
     // every global load it waits for is exposed.  The row fragments of q / dO and the row terms (lse, D) of tile qt+1 are
     // requested at the top of iteration qt, the transposed pieces of tile qt before its first MFMA: by the time they are
@@ -125,15 +144,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(
         // transposed pieces of THIS tile (A operands of the dV / dK products), requested before the S / dP products
         union TP { bf16x8 v; uint2 h[2]; };
         TP af[2][DT], bfr[2][DT];
-        auto load_tr = [&](int s2) __attribute__((always_inline)) {
-            const int qo = q0 + 16 * s2 + 4 * lh;        // tokens qo..qo+3 and qo+8..qo+11 (padded copy: in bounds)
+        auto load_tr = [&](int s2) __attribute__((always_inline)) {     // one coalesced 16-byte load per lane and fragment
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                const size_t row = (size_t)(dt * 32 + lr) * n_pad;
-                af[s2][dt].h[0] = *reinterpret_cast<const uint2*>(doTh + row + qo);
-                af[s2][dt].h[1] = *reinterpret_cast<const uint2*>(doTh + row + qo + 8);
-                bfr[s2][dt].h[0] = *reinterpret_cast<const uint2*>(qTh + row + qo);
-                bfr[s2][dt].h[1] = *reinterpret_cast<const uint2*>(qTh + row + qo + 8);
+                const size_t fo = tfrag_lane<HS>(head, n_pad, tile0 + qt, s2, dt, lane);
+                af[s2][dt].v = *reinterpret_cast<const bf16x8*>(doT + fo);
+                bfr[s2][dt].v = *reinterpret_cast<const bf16x8*>(qT + fo);
             }
         };
         if (PIPE) load_tr(0);
@@ -170,13 +186,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(
             }
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                if (!PIPE) {                               // hs 128: one piece pair at a time (8 registers live)
-                    const int qo = q0 + 16 * s2 + 4 * lh;
-                    const size_t row = (size_t)(dt * 32 + lr) * n_pad;
-                    af[s2][dt].h[0] = *reinterpret_cast<const uint2*>(doTh + row + qo);
-                    af[s2][dt].h[1] = *reinterpret_cast<const uint2*>(doTh + row + qo + 8);
-                    bfr[s2][dt].h[0] = *reinterpret_cast<const uint2*>(qTh + row + qo);
-                    bfr[s2][dt].h[1] = *reinterpret_cast<const uint2*>(qTh + row + qo + 8);
+                if (!PIPE) {                               // hs 128: one fragment pair at a time (8 registers live)
+                    const size_t fo = tfrag_lane<HS>(head, n_pad, tile0 + qt, s2, dt, lane);
+                    af[s2][dt].v = *reinterpret_cast<const bf16x8*>(doT + fo);
+                    bfr[s2][dt].v = *reinterpret_cast<const bf16x8*>(qT + fo);
                 }
                 dvT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s2][dt].v, pf.v, dvT[dt], 0, 0, 0);    // [d][key]
                 dkT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[s2][dt].v, dsf.v, dkT[dt], 0, 0, 0);
@@ -284,7 +297,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dqT[dt][r] = 0.f;
-    const bf16_t* kTg = kT + (size_t)g * HS * n_pad + ps;
+    const int tile0 = ps >> 5;
     for (int kt = 0; kt <= qt; ++kt) {
         const int key0 = kt * 32;
         int key = key0 + lr;
@@ -313,14 +326,10 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(
             union { bf16x8 v; uint32_t u[4]; } dsf;
 #pragma unroll
             for (int j = 0; j < 4; ++j) dsf.u[j] = pack2bf(st[8 * s2 + 2 * j], st[8 * s2 + 2 * j + 1]);
-            const int ko = key0 + 16 * s2 + 4 * lh;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                const size_t row = (size_t)(dt * 32 + lr) * n_pad;
-                union { bf16x8 v; uint2 h[2]; } af;
-                af.h[0] = *reinterpret_cast<const uint2*>(kTg + row + ko);
-                af.h[1] = *reinterpret_cast<const uint2*>(kTg + row + ko + 8);
-                dqT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.v, dsf.v, dqT[dt], 0, 0, 0);   // [d][q]
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(kT + tfrag_lane<HS>(g, n_pad, tile0 + kt, s2, dt, lane));
+                dqT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, dsf.v, dqT[dt], 0, 0, 0);   // [d][q]
             }
         }
     }

@@ -205,7 +205,10 @@ int dh_tn_accum_f32(const dh_bf16* a, int lda, const dh_bf16* b, int ldb, float*
                     int M, int N, float scale, int accumulate, void* work, void* stream);
 /* out[row] = sum_d a[row,d]*b[row,d]   (softmax-backward row term D = rowsum(dO*O)) */
 int dh_rowdot_f32(const dh_bf16* a, const dh_bf16* b, float* out, int64_t rows, int hs, void* stream);
-/* src [n_tok, heads, hs] -> dst [heads, hs, n_pad], sequence i placed at pad_start[i] (multiple of 32) */
+/* src [n_tok, heads, hs] -> dst (heads * hs * n_pad elements, zero-initialised by the caller): the token-contiguous copy the
+ * backward kernels take as a transposed MFMA operand, in FRAGMENT ORDER (csrc/attention_bwd.hip: tfrag_off — per head and 32-token
+ * tile the 2 x hs/32 fragments of v_mfma_f32_32x32x16_bf16, 64 lanes x 8 values each, so a wave's fragment is one contiguous 1-KiB
+ * load); sequence i starts at padded token pad_start[i] (multiple of 32). */
 int dh_transpose_pad_bf16(const dh_bf16* src, dh_bf16* dst, const int32_t* tok_seq,
                           const int32_t* q_start, const int32_t* pad_start, int n_tok, int heads,
                           int hs, int n_pad, void* stream);

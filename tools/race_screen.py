@@ -84,5 +84,21 @@ for (M, d, I) in [(256, 2048, 5632), (1024, 2048, 5632), (100, 512, 768)]:
         check(f"partials rows alone M={M} d={d} it={it}", ops.linear_partial(x[32:64].contiguous(), wq, A, ksplit=ks), parts[:, 32:64])
     print(f"decode GEMMs M={M} d={d}: {REPS} runs done", flush=True)
 lib.dh_set_tuning(6, 129); lib.dh_set_tuning(7, 1 << 30); lib.dh_set_tuning(8, 0); lib.dh_set_tuning(4, 0)
+# ---- round 3: the fp8 256-tile (sixteen waves, two-stage __syncthreads loop) against the 128-tile, ragged shapes
+def q8(*s):
+    return (torch.randn(*s, device=D, generator=g) * 0.5).to(torch.float8_e4m3fn).view(torch.uint8)
+for (M, N, K) in [(1536, 6144, 4096), (777, 1024, 512), (300, 4096, 1792), (4096, 14336, 4096)]:
+    for it in range(max(REPS // 4, 2)):
+        x8, w8, w28 = q8(M, K), q8(N, K), q8(N, K)
+        xs, ws = torch.rand(M, device=D) + 0.5, torch.rand(N, device=D) * 0.01 + 0.005
+        r = rn(M, N)
+        outs = {}
+        for tile in (128, 256):
+            lib.dh_set_tuning(19, tile)
+            outs[tile] = (ops.linear_fp8(x8, xs, w8, ws, resid=r, kernel=1), ops.linear_fp8(x8, xs, w8, ws, epilogue=ops.EPI_SWIGLU, w2q=w28, w2_scale=ws, kernel=1))
+        lib.dh_set_tuning(19, 0)
+        check(f"fp8 256-tile vs 128-tile plain+resid M={M} N={N} K={K} it={it}", outs[256][0], outs[128][0])
+        check(f"fp8 256-tile vs 128-tile swiglu M={M} N={N} K={K} it={it}", outs[256][1], outs[128][1])
+    print(f"fp8 tiles {M}x{N}x{K} done", flush=True)
 print("race screen:", "CLEAN" if bad == 0 else f"{bad} MISMATCHES")
 sys.exit(1 if bad else 0)
