@@ -162,7 +162,10 @@ __global__ __launch_bounds__(256) void tn_accum_kernel(const bf16_t* __restrict_
 // PACKED micro-batches (round 3: P x 560 tokens per launch) make the token loop the long dimension: the grid's z splits the
 // tokens into chunks of `tchunk`; with gridDim.z > 1 a block writes its chunk's plain fp32 sums to part[z][M][N] and
 // tn_reduce_kernel adds the chunks in index order (deterministic, no atomics), applies `scale` and accumulates.
-template <bool LARGE_IS_M>
+// SB: 16-wide groups of the SMALL dimension a block owns (1, or 3 for the 48-row QKV LoRA-A gradient: the large operand — 2048
+// columns of the packed tokens — is then read once instead of three times; the sums are unchanged: per output the same 16 wave
+// partials in the same order).
+template <bool LARGE_IS_M, int SB = 1>
 __global__ __launch_bounds__(1024) void tn_accum_wide_kernel(const bf16_t* __restrict__ a, int lda, const bf16_t* __restrict__ b,
                                                              int ldb, float* __restrict__ out, int ldo, int T, int M, int N,
                                                              float scale, int accumulate, int tchunk) {
@@ -181,37 +184,47 @@ __global__ __launch_bounds__(1024) void tn_accum_wide_kernel(const bf16_t* __res
     const bf16_t* small = LARGE_IS_M ? b : a;
     const int ldbig = LARGE_IS_M ? lda : ldb, ldsm = LARGE_IS_M ? ldb : lda;
     const int L = LARGE_IS_M ? M : N;
-    const int l = blockIdx.x * 64 + lane, s0 = blockIdx.y * 16;
+    const int l = blockIdx.x * 64 + lane, s0 = blockIdx.y * 16 * SB;
     const int lc = l < L ? l : L - 1;
-    float acc[16];
+    float acc[SB][16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    for (int sb = 0; sb < SB; ++sb)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[sb][j] = 0.f;
     for (int t0 = wave; t0 < T; t0 += NWV * UN) {
         bf16_t xv[UN];
-        uint4 lo[UN], hi[UN];
+        uint4 lo[UN][SB], hi[UN][SB];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {           // all loads of the round first: the loop is latency-bound otherwise
             const int t = min(t0 + u * NWV, T - 1);
             xv[u] = big[(size_t)t * ldbig + lc];
-            lo[u] = *reinterpret_cast<const uint4*>(small + (size_t)t * ldsm + s0);
-            hi[u] = *reinterpret_cast<const uint4*>(small + (size_t)t * ldsm + s0 + 8);
+#pragma unroll
+            for (int sb = 0; sb < SB; ++sb) {
+                lo[u][sb] = *reinterpret_cast<const uint4*>(small + (size_t)t * ldsm + s0 + 16 * sb);
+                hi[u][sb] = *reinterpret_cast<const uint4*>(small + (size_t)t * ldsm + s0 + 16 * sb + 8);
+            }
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const float x = t0 + u * NWV < T ? bf2f(xv[u]) : 0.f;
-            const bf16_t* pl = reinterpret_cast<const bf16_t*>(&lo[u]);
-            const bf16_t* ph = reinterpret_cast<const bf16_t*>(&hi[u]);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                acc[j] = fmaf(x, bf2f(pl[j]), acc[j]);
-                acc[8 + j] = fmaf(x, bf2f(ph[j]), acc[8 + j]);
+            for (int sb = 0; sb < SB; ++sb) {
+                const bf16_t* pl = reinterpret_cast<const bf16_t*>(&lo[u][sb]);
+                const bf16_t* ph = reinterpret_cast<const bf16_t*>(&hi[u][sb]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    acc[sb][j] = fmaf(x, bf2f(pl[j]), acc[sb][j]);
+                    acc[sb][8 + j] = fmaf(x, bf2f(ph[j]), acc[sb][8 + j]);
+                }
             }
         }
     }
 #pragma unroll
-    for (int j = 0; j < 16; ++j) red[wave][j][lane] = acc[j];
-    __syncthreads();
-    {
+    for (int sb = 0; sb < SB; ++sb) {
+        if (sb) __syncthreads();                 // the previous group's sums have been read
+#pragma unroll
+        for (int j = 0; j < 16; ++j) red[wave][j][lane] = acc[sb][j];
+        __syncthreads();
         const int o = threadIdx.x;               // 1024 outputs, one per thread
         const int j = LARGE_IS_M ? (o & 15) : (o >> 6), ll = LARGE_IS_M ? (o >> 4) : (o & 63);
         const int lg = blockIdx.x * 64 + ll;
@@ -219,7 +232,7 @@ __global__ __launch_bounds__(1024) void tn_accum_wide_kernel(const bf16_t* __res
             float v = 0.f;
 #pragma unroll
             for (int w = 0; w < NWV; ++w) v += red[w][j][ll];
-            float* p = LARGE_IS_M ? out + (size_t)lg * ldo + s0 + j : out + (size_t)(s0 + j) * ldo + lg;
+            float* p = LARGE_IS_M ? out + (size_t)lg * ldo + s0 + 16 * sb + j : out + (size_t)(s0 + 16 * sb + j) * ldo + lg;
             *p = (accumulate ? *p : 0.f) + scale * v;
         }
     }
@@ -312,11 +325,14 @@ extern "C" int dh_tn_accum_f32(const dh_bf16* a, int lda, const dh_bf16* b, int 
         // long token loops (packed micro-batches) are split over the grid's z when the caller brought scratch
         const int nz = work != nullptr && T > 2 * TN_CHUNK ? cdiv(T, TN_CHUNK) : 1;
         float* dst = nz > 1 ? (float*)work : out;
+        // SB = 3 (the 48-row QKV LoRA-A gradient in one block: the large operand read once instead of three times) was measured:
+        // 520 us per call against ~260 — 48 accumulators + 24 operand registers per token round do not fit the 128 VGPRs of a
+        // 1024-thread block.  Not dispatched.
         if (n_small)
-            hipLaunchKernelGGL(tn_accum_wide_kernel<true>, dim3(cdiv(M, 64), N / 16, nz), dim3(1024), 0, st, a, lda, b, ldb, dst, ldo,
+            hipLaunchKernelGGL((tn_accum_wide_kernel<true, 1>), dim3(cdiv(M, 64), N / 16, nz), dim3(1024), 0, st, a, lda, b, ldb, dst, ldo,
                                T, M, N, scale, accumulate, TN_CHUNK);
         else
-            hipLaunchKernelGGL(tn_accum_wide_kernel<false>, dim3(cdiv(N, 64), M / 16, nz), dim3(1024), 0, st, a, lda, b, ldb, dst, ldo,
+            hipLaunchKernelGGL((tn_accum_wide_kernel<false, 1>), dim3(cdiv(N, 64), M / 16, nz), dim3(1024), 0, st, a, lda, b, ldb, dst, ldo,
                                T, M, N, scale, accumulate, TN_CHUNK);
         if (nz > 1)
             hipLaunchKernelGGL(tn_reduce_kernel, dim3(cdiv(M * N, 256)), dim3(256), 0, st, (const float*)work, nz, out, ldo, M, N, scale,
