@@ -306,15 +306,15 @@ def test_train_micro_step_tinyllama_shape(golden):
 
 def test_train_micro_step_full_depth(golden):
     """The same micro-step at FULL depth: all 22 layers of TinyLlama-1.1B (VERDICT r02 missing #7), T = 560, against the REFERENCE's
-    autograd in fp32, bf16-true and bf16-mixed (tests/golden/train_tinyllama_full: the LoRA gradients of layers 0, 10 and 21 in full,
-    max |g| and the norm of every other layer's from the fp32 run).  Through 22 layers of bf16 activations the backward signal
+    autograd in fp32, bf16-true and bf16-mixed (tests/golden/train_tinyllama_full: the fp32 LoRA gradients of layers 0 and 21 in full with
+    the bf16 / mixed runs' distances to them, max |g| and the norm of every other layer's fp32 gradient).  Through 22 layers of bf16 activations the backward signal
     of layer 0 has passed every kernel of the path: HIP's distance to the fp32 gradient within 1.3x the reference's own bf16 runs'."""
     from dualhyp_amd import GPT, Config, chunked_cross_entropy
     from dualhyp_amd.synth import synth_state_dict
     from dualhyp_amd.train import prepare_for_training
     t, meta = golden("train_tinyllama_full")
     cfg = Config(**meta["config"])
-    assert cfg.n_layer == 22 and meta["keep_layers"] == [0, 10, 21]
+    assert cfg.n_layer == 22 and meta["keep_layers"] == [0, 21]
     m = GPT(cfg).to(device=DEV, dtype=torch.bfloat16)
     m.load_state_dict(synth_state_dict(cfg, seed=meta["seed"], norm_jitter=meta["norm_jitter"], device=DEV))
     m.cpu_rsqrt_vec_width = 32
@@ -339,9 +339,7 @@ def test_train_micro_step_full_depth(golden):
             continue
         g32 = t[f"fp32.grad.{n}"].float()
         scale = g32.abs().max().item()
-        e = {"hip": (g - g32).abs().max().item() / scale,
-             "bf16": (t[f"bf16.grad.{n}"].float() - g32).abs().max().item() / scale,
-             "mixed": (t[f"mixed.grad.{n}"].float() - g32).abs().max().item() / scale}
+        e = {"hip": (g - g32).abs().max().item() / scale, "bf16": t[f"bf16.graderr.{n}"].item(), "mixed": t[f"mixed.graderr.{n}"].item()}
         for k in worst:
             worst[k] = max(worst[k], e[k])
         assert e["hip"] <= max(1.3 * max(e["bf16"], e["mixed"]), 0.02), f"{n}: {e}"

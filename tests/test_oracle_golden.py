@@ -260,13 +260,16 @@ def test_train_micro_step_full_depth(golden, tag, dtype, autocast):
     assert abs(loss.item() - t[f"{tag}.train_loss"].float().item()) <= (1e-5 if tag == "fp32" else 4e-3)
     checked = 0
     for k, g in grads.items():
-        if f"{tag}.grad.{k}" not in t:
+        if f"fp32.grad.{k}" not in t:
             continue
-        want = t[f"{tag}.grad.{k}"].float()
-        tol = 1e-4 if tag == "fp32" else 2e-2
-        assert (g.float() - want).abs().max().item() <= tol * want.abs().max().item() + 1e-9, (tag, k)
+        g32 = t[f"fp32.grad.{k}"].float()
+        if tag == "fp32":
+            assert (g.float() - g32).abs().max().item() <= 1e-4 * g32.abs().max().item() + 1e-9, (tag, k)
+        else:       # the reference's own distance to its fp32 gradient, reproduced
+            err = ((g.float() - g32).abs().max() / g32.abs().max()).item()
+            assert abs(err - t[f"{tag}.graderr.{k}"].item()) <= 0.25 * t[f"{tag}.graderr.{k}"].item() + 2e-3, (tag, k, err)
         checked += 1
-    assert checked == 12       # 3 kept layers x (attn A, B, proj A, B)
+    assert checked == 8        # 2 kept layers x (attn A, B, proj A, B)
 
 
 @SLOW
