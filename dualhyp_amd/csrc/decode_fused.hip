@@ -9,8 +9,6 @@
 // rope + KV-cache append + split-KV attention + combine into one kernel.
 #include "common.h"
 
-int g_attn_persist_blocks = 512;
-
 namespace {
 
 constexpr int DCOLS = 16;   // padded head columns of the attention partials
@@ -33,20 +31,10 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 1 : (NW == 6 ? 3 : (HS == 64 ? 
     bf16_t* __restrict__ y, int n_head, int n_groups, int s_max, float scale) {
     constexpr int KS = HS / 16, DT = HS / 32, HALF = HS / 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int pair = blockIdx.x, seq = pair / n_groups, g = pair % n_groups;
     const int q_per_kv = n_head / n_groups;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
-    const int n_pairs = n_seq * n_groups;
-    // PERSISTENT blocks (round 3, grids of more than two blocks per CU): a block walks the (sequence, group) pairs bid, bid + grid,
-    // ... and requests the first key tile of its NEXT pair before the combine of the current one, so the HBM stream does not
-    // pause for every pair's combine, block turnover and LoRA / rope prologue.  Same arithmetic per pair.
-    constexpr int PF = NW == 6 ? 2 : 1;
-    struct VF { bf16x8 v; };
-    struct Tile { bf16x8 kf[KS]; VF vf[DT][2]; };
-    Tile tl[PF];
-    bool have_next_tile = false;
-    for (int pair = blockIdx.x; pair < n_pairs; pair += gridDim.x) {
-    const int seq = pair / n_groups, g = pair % n_groups;
     const int slot = seq_slot[seq];
     const int len = kv_len[seq], pos = len - 1;          // the new token sits at position len-1
     // LDS carve (all offsets multiples of 16 B)
@@ -65,26 +53,27 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 1 : (NW == 6 ? 3 : (HS == 64 ? 
     // tiles of operands in flight per wave.  8 waves: one (128 VGPRs, two blocks per CU at hs 64); SIX waves (round 3, hs 64): two —
     // three waves per SIMD leave 168 VGPRs, and at ~544 keys (17 tiles = 3 per wave) the third tile's loads are issued right
     // after the first tile is consumed and land under the second: no tile waits for an exposed HBM round trip
+    constexpr int PF = NW == 6 ? 2 : 1;
+    struct VF { bf16x8 v; };
+    struct Tile { bf16x8 kf[KS]; VF vf[DT][2]; };
+    Tile tl[PF];
     const bf16_t* kbase = k_cache + ((size_t)slot * n_groups + g) * s_max * HS;
     const bf16_t* vbase = vT_cache + ((size_t)slot * n_groups + g) * HS * s_max;
     const int n_tiles = (pos + 31) / 32;
     // the caches are in MFMA-fragment order (common.h): a tile is 8 coalesced 1-KiB loads
-    auto load_tile_from = [&](Tile& T, const bf16_t* kb, const bf16_t* vb, int t) __attribute__((always_inline)) {
+    auto load_tile = [&](Tile& T, int t) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
-            T.kf[ks] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(kb + kfrag_blk<HS>(t, ks) + lane * 8));
+            T.kf[ks] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(kbase + kfrag_blk<HS>(t, ks) + lane * 8));
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
-                T.vf[dt][s2].v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(vb + vfrag_blk<HS>(t, dt, s2) + lane * 8));
+                T.vf[dt][s2].v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(vbase + vfrag_blk<HS>(t, dt, s2) + lane * 8));
     };
-    auto load_tile = [&](Tile& T, int t) __attribute__((always_inline)) { load_tile_from(T, kbase, vbase, t); };
-    if (!have_next_tile) {                              // block-uniform: the first pair of the block (or PF > 1)
 #pragma unroll
-        for (int p = 0; p < PF; ++p)
-            if (wave + NW * p < n_tiles) load_tile(tl[p], wave + NW * p);
-    }
+    for (int p = 0; p < PF; ++p)
+        if (wave + NW * p < n_tiles) load_tile(tl[p], wave + NW * p);
 
     const float* row0 = qkv32 + (size_t)seq * ldq;
     const size_t pstride = (size_t)n_seq * ldq;
@@ -233,16 +222,6 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 1 : (NW == 6 ? 3 : (HS == 64 ? 
             if (base + NW * (PF + p) < n_tiles) load_tile(tl[p], base + NW * (PF + p));    // its set is free again
         }
     }
-    // the next pair's first tile (PF == 1): its registers are free now, and the loads run under this pair's combine and the
-    // next pair's prologue
-    have_next_tile = false;
-    if (PF == 1 && pair + (int)gridDim.x < n_pairs) {
-        const int np = pair + gridDim.x, nseq = np / n_groups, ng = np % n_groups;
-        const int nslot = seq_slot[nseq], npos = kv_len[nseq] - 1;
-        if (wave < (npos + 31) / 32)
-            load_tile_from(tl[0], k_cache + ((size_t)nslot * n_groups + ng) * s_max * HS, vT_cache + ((size_t)nslot * n_groups + ng) * HS * s_max, wave);
-        have_next_tile = true;
-    }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     if (lr < q_per_kv) {
         if (lh == 0) {
@@ -276,8 +255,6 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 1 : (NW == 6 ? 3 : (HS == 64 ? 
         }
         y[(size_t)seq * n_head * HS + (g * q_per_kv + h) * HS + d] = f2bf(O / L);
     }
-    __syncthreads();                                    // LDS is reused by the block's next pair
-    }   // pairs of this block
 }
 
 #ifndef DH_ATTN_WAVES64
@@ -427,10 +404,7 @@ extern "C" int dh_attn_decode_fused_bf16(const float* qkv32, int n_part, int pai
     if (n_seq <= 0) return 0;
     const float scale = 1.0f / sqrtf((float)hs);
     hipStream_t s = (hipStream_t)stream;
-    // more than g_attn_persist_blocks pairs: that many persistent blocks (two per CU at hs 64) walk them (dh_set_tuning key 22; 0 = one
-    // block per pair)
-    const int n_pairs = n_seq * n_groups;
-    dim3 grid(g_attn_persist_blocks > 0 && n_pairs > g_attn_persist_blocks ? g_attn_persist_blocks : n_pairs);
+    dim3 grid(n_seq * n_groups);
 #define ATT_LAUNCH(HSV, PM)                                                                                           \
     hipLaunchKernelGGL((attn_decode_fused_kernel<HSV, PM, attn_fused_waves<HSV>()>), grid, dim3(64 * attn_fused_waves<HSV>()), attn_fused_lds<HSV>(), s, qkv32, n_part, pairs, n_seq,  \
                        qkv_dim + n_ext, qkv_dim, lora_b, lora_scale, split0, split1, cos, sin, seq_slot, kv_len, k_cache,  \
