@@ -158,7 +158,7 @@ class HypothesesDataset:
     def __init__(self, json_path_or_items, tokenizer, prompts_format: str = "DualHyp", nhyps_key: str = "nhyps_asr",
                  max_nhyps: Optional[int] = None, max_input_length: int = 0, language: Optional[str] = None,
                  mask_threshold: Optional[float] = None, time_window: float = 0.4, seed: Optional[int] = None,
-                 enc_features=None) -> None:
+                 enc_features=None, leave_masks: bool = False) -> None:
         items = json_path_or_items
         if isinstance(items, (str, bytes)) or hasattr(items, "__fspath__"):
             with open(items, encoding="utf-8") as f:
@@ -170,6 +170,9 @@ class HypothesesDataset:
         # RelPrompt fine-tune: callable (asr_item, vsr_item) -> (audio encoder features [T_a, whisper_dim], visual
         # [T_v, raven_dim]); the Whisper / BRAVEn encoders themselves are upstream of this path (finetune/relprompt.py:346-352)
         self.enc_features = enc_features
+        # RelPrompt inference (inference/relprompt.py:113-153): the prompt keeps its <<<ASR_MASKS>>> / <<<VSR_MASKS>>> placeholders;
+        # the harness fills them with the classifiers' predictions and re-encodes
+        self.leave_masks = leave_masks
         self.tokenizer, self.fmt, self.nhyps_key = tokenizer, prompts_format, nhyps_key
         self.max_nhyps, self.max_input_length, self.language = max_nhyps, max_input_length, language
         self.mask_threshold = mask_threshold
@@ -191,7 +194,7 @@ class HypothesesDataset:
             else:
                 _, al = chunk_reliability(noise_mask(s1, "audio", self.mask_threshold), self.audio_chunk)
                 _, vl = chunk_reliability(noise_mask(s2, "video", self.mask_threshold), self.video_chunk)
-                prompt = relprompt_prompt(s1, s2, al, vl, self.max_nhyps)
+                prompt = relprompt_prompt(s1, s2, al, vl, self.max_nhyps, leave_masks=self.leave_masks)
         ex = encode_example(self.tokenizer, prompt, s1["Caption"], self.max_input_length)
         ex["uid"], ex["ground_truth"] = s1.get("Uid", ""), s1.get("Caption", "")
         if self.fmt == "RelPrompt":

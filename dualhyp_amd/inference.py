@@ -152,9 +152,32 @@ def result(adapter_path: str, model, tokenizer, args, rank: int = 0, world: int 
     fmt = args.prompts_format
     if args.dual_hypotheses and "Dual" not in fmt and fmt != "RelPrompt":
         print("Warning: dual hypotheses is enabled, but prompts format is not Dual.")
+    # RelPrompt with encoder features at hand: the prompt's mask tokens are PREDICTED by the reliability classifiers
+    # (inference/relprompt.py:113-153); without features the ground-truth chunk labels of the corruption records are used
+    feats_dir = getattr(args, "enc_features_dir", None) if fmt == "RelPrompt" else None
+    enc_features = None
+    if feats_dir:
+        def enc_features(s1, s2, _d=Path(feats_dir)):
+            f = torch.load(_d / f"{s1['Uid']}.pt", map_location="cpu")
+            return f["audio"].float(), f["visual"].float()
     ds = HypothesesDataset(args.test_path, tokenizer, prompts_format=fmt if (args.dual_hypotheses or fmt == "RelPrompt") else "GER",
-                           nhyps_key=args.nhyps_key, max_nhyps=args.max_nhyps, language=args.language, seed=args.seed)
+                           nhyps_key=args.nhyps_key, max_nhyps=args.max_nhyps, language=args.language, seed=args.seed,
+                           mask_threshold=getattr(args, "mask_threshold", None), time_window=getattr(args, "time_window", 0.4),
+                           enc_features=enc_features, leave_masks=bool(feats_dir))
     examples = [ds[i] for i in range(len(ds))]
+    mask_stats = None
+    if feats_dir:
+        from .relprompt import predicted_mask_prompt
+        hit = {"audio": [0, 0], "visual": [0, 0]}
+        for ex in examples:
+            prompt, a, v = predicted_mask_prompt(model, ex["input_no_response"], ex["audio_enc_features"], ex["visual_enc_features"])
+            ex["input_no_response"] = prompt
+            ex["input_ids_no_response"] = torch.tensor(tokenizer.encode(prompt), dtype=torch.int64)    # re-encoded with the predicted masks
+            for name, pred, tgt in (("audio", a, ex["audio_mask_targets"]), ("visual", v, ex["visual_mask_targets"])):
+                n = min(pred.numel(), tgt.numel())                                                   # trimmed to the shorter, as the reference
+                hit[name][0] += int((pred[:n] == tgt[:n]).sum())
+                hit[name][1] += n
+        mask_stats = {f"{k}_mask_accuracy": h[0] / max(h[1], 1) for k, h in hit.items()}
     eos = tokenizer.eos_token_id
 
     def gen(prompts):
@@ -166,6 +189,10 @@ def result(adapter_path: str, model, tokenizer, args, rank: int = 0, world: int 
     out = run_inference(gen, examples, tokenizer.decode, batch_size=args.decode_batch, rank=rank, world=world,
                         device="cpu" if os.environ.get("DUALHYP_DP_REHEARSAL") == "1" or world == 1 else model.transformer.wte.weight.device)
     out["adapter_path"] = adapter_path
+    if mask_stats:
+        out.update(mask_stats)
+        if rank == 0:
+            print("reliability masks predicted by the classifiers:", mask_stats)
     if rank == 0:
         n = out["n"]
         to_json = list(out["predictions"])
@@ -210,6 +237,12 @@ def main(argv: Optional[Sequence[str]] = None) -> Dict[str, Any]:
     p.add_argument("--decode_batch", type=int, default=32, help="utterances per packed prefill / joint decode")
     p.add_argument("--max_new_tokens", type=int, default=150, help="inference/ger.py:71")
     p.add_argument("--predict_dir", type=str, default=None)
+    # RelPrompt (inference/relprompt.py): chunk geometry of the reliability masks; with --enc_features_dir (<dir>/<Uid>.pt =
+    # {'audio': [T, whisper_dim], 'visual': [T, raven_dim]}: the encoders are upstream of this path) the masks are predicted
+    p.add_argument("--mask_threshold", type=int, default=None)
+    p.add_argument("--time_window", type=float, default=0.4)
+    p.add_argument("--pool_size", type=int, default=10)
+    p.add_argument("--enc_features_dir", type=str, default=None)
     args = p.parse_args(argv)
     if args.apply_chat_template:
         raise NotImplementedError("--apply_chat_template is outside the hot path")
@@ -222,6 +255,8 @@ def main(argv: Optional[Sequence[str]] = None) -> Dict[str, Any]:
     cfg = config_from_args(args)
     tokenizer = load_tokenizer(args.llm_checkpoint, args.tokenizer)
     rel = args.prompts_format == "RelPrompt"
+    if rel:
+        cfg.pool_size = args.pool_size
     model = (RelGPT if rel else GPT)(cfg)
     if rel:                                        # inference/relprompt.py:341-342
         tokenizer.add_reliability_tokens(cfg.padded_vocab_size)

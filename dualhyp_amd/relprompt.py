@@ -104,6 +104,19 @@ def labels_to_indices(labels_list, device, prefix: str = "") -> torch.Tensor:
     return torch.tensor(rows, device=device)
 
 
+@torch.no_grad()
+def predicted_mask_prompt(model: nn.Module, prompt_with_placeholders: str, audio_enc_features: torch.Tensor,
+                          visual_enc_features: torch.Tensor, mask_tokens=("<<C>>", "<<M>>", "<<N>>")):
+    """inference/relprompt.py:113-153 for one utterance: per-chunk reliability classes from the two classifiers (arg-max of
+    their logits) become the mask tokens of the prompt.  -> (prompt, audio class indices, visual class indices)."""
+    dev = next(model.parameters()).device
+    a = model.audio_noise_classifier(audio_enc_features.to(dev).unsqueeze(0)).float().argmax(-1)[0].cpu()
+    v = model.visual_noise_classifier(visual_enc_features.to(dev).unsqueeze(0)).float().argmax(-1)[0].cpu()
+    prompt = (prompt_with_placeholders.replace("<<<ASR_MASKS>>>", "".join(mask_tokens[i] for i in a.tolist()))
+              .replace("<<<VSR_MASKS>>>", "".join(mask_tokens[i] for i in v.tolist())))
+    return prompt, a, v
+
+
 def mark_only_lora_as_trainable(model: nn.Module, bias: str = "none") -> None:
     """ger/relprompt.py:79-119: as ger/lora.py's, but the noise classifiers stay trainable."""
     from .gpt import mark_only_lora_as_trainable as base

@@ -219,3 +219,57 @@ def test_relprompt_finetune_harness_trains_the_classifiers(tmp_path):
     torch.manual_seed(1337); random.seed(1337)
     fresh = RelGPT(cfg)
     assert not torch.equal(fresh.audio_noise_classifier.classifier.bias.detach().float(), ck["audio_noise_classifier.classifier.bias"].float())
+
+
+def test_relprompt_inference_predicts_the_masks(tmp_path):
+    """inference/relprompt.py:113-153: with encoder features at hand the prompt's reliability tokens come from the classifiers
+    (arg-max per chunk), the prompt is re-encoded with them, and the predictions are scored against the chunk labels of the
+    corruption records.  Checked against the same steps done by hand on the module API."""
+    from dualhyp_amd import Config
+    from dualhyp_amd.data import HypothesesDataset
+    from dualhyp_amd.relprompt import GPT as RelGPT, predicted_mask_prompt
+    from dualhyp_amd.synth import synth_state_dict
+    from dualhyp_amd.tokenizer import ByteTokenizer
+    items = merged_items(3)
+    (tmp_path / "test.json").write_text(json.dumps(items))
+    ckpt_dir = tmp_path / "checkpoints" / "parity-harness"
+    ckpt_dir.mkdir(parents=True)
+    feats = tmp_path / "feats"
+    feats.mkdir()
+    g = torch.Generator().manual_seed(1)
+    for it in items:
+        torch.save({"audio": torch.randn(100, 1280, generator=g), "visual": torch.randn(50, 1024, generator=g)}, feats / f"{it['Uid']}.pt")
+    # a checkpoint with known classifier weights
+    cfg = Config.from_name("parity-harness", r=16, alpha=16, dropout=0.05, to_query=True, to_key=True, to_value=True, to_projection=True)
+    torch.manual_seed(7)
+    m = RelGPT(cfg)
+    m.load_state_dict(synth_state_dict(cfg, seed=31, weight_scale=4.0, embed_scale=64.0, head_tie=1.0), strict=False)
+    m.resize_token_embeddings(3)
+    run = tmp_path / "runs" / "rp"
+    run.mkdir(parents=True)
+    torch.save({"model": {k: v.detach() for k, v in m.state_dict().items()}}, run / "best_model.pth")
+    cmd = [sys.executable, "-m", "dualhyp_amd.inference", "--test_path", str(tmp_path / "test.json"), "--model_path", str(run / "best_model.pth"),
+           "--llm_checkpoint", str(ckpt_dir), "--prompts_format", "RelPrompt", "--tokenizer", "byte", "--max_new_tokens", "6",
+           "--decode_batch", "2", "--enc_features_dir", str(feats)]
+    out = subprocess.run(cmd, cwd=tmp_path, env=_env(), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    assert "reliability masks predicted by the classifiers" in out.stdout
+    js = json.loads((run / "predictions" / "best_model.json").read_text())
+    assert len(js) == 3 + 2
+    # by hand: the same model, the dataset with placeholders left in, the classifiers' arg-max tokens
+    tok = ByteTokenizer()
+    tok.add_reliability_tokens(cfg.padded_vocab_size)
+    mg = m.to(device="cuda:0", dtype=torch.bfloat16).eval()
+    ds = HypothesesDataset(str(tmp_path / "test.json"), tok, prompts_format="RelPrompt", seed=1337, leave_masks=True,
+                           enc_features=lambda s1, s2: tuple(torch.load(feats / f"{s1['Uid']}.pt")[k].float() for k in ("audio", "visual")))
+    accs = []
+    for i in range(len(ds)):
+        ex = ds[i]
+        assert "<<<ASR_MASKS>>>" in ex["input_no_response"] and "<<<VSR_MASKS>>>" in ex["input_no_response"]
+        prompt, a, v = predicted_mask_prompt(mg, ex["input_no_response"], ex["audio_enc_features"], ex["visual_enc_features"])
+        assert "<<<" not in prompt and a.numel() == 5 and v.numel() == 5 and prompt.count("<<") == 10
+        accs.append((int((a == ex["audio_mask_targets"][:5]).sum()), int((v == ex["visual_mask_targets"][:5]).sum())))
+    want_a, want_v = sum(x for x, _ in accs) / 15, sum(y for _, y in accs) / 15
+    import re
+    got = re.search(r"'audio_mask_accuracy': ([0-9.]+), 'visual_mask_accuracy': ([0-9.]+)", out.stdout)
+    assert got and abs(float(got.group(1)) - want_a) < 1e-9 and abs(float(got.group(2)) - want_v) < 1e-9, (out.stdout[-500:], want_a, want_v)
