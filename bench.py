@@ -169,7 +169,10 @@ def main() -> None:
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # under a launcher (WORLD_SIZE set) the process group is created even for ONE rank, so the collectives of the N > 1 path
+    # (barrier, MAX all-reduce of the wall time, the fine-tune's flat-bucket all-reduce) run through RCCL on a one-GPU box too
+    use_pg = world > 1 or ("WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ)
+    if use_pg:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
@@ -196,7 +199,7 @@ def main() -> None:
     del sd
     model.eval()
     if wl.get("train"):
-        return bench_finetune(a, wl, cfg, model, dev, rank, world, rehearsal)
+        return bench_finetune(a, wl, cfg, model, dev, rank, world, rehearsal, use_pg)
     if wl["fp8"]:
         from dualhyp_amd import quantize_model_fp8
         quantize_model_fp8(model)                  # merge_lora_weights, then e4m3 rows + channel scales
@@ -214,7 +217,7 @@ def main() -> None:
     batches = [mine[i * B:(i + 1) * B] for i in range(n_batches)]
 
     def barrier():
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -267,7 +270,7 @@ def main() -> None:
         e.set_timing(False)
     timed_prompts = [p for b in batches[n_warm:] for p in b]
     assert all(o.numel() == p.numel() + NEW_TOKENS for o, p in zip([o for out in outs for o in out], timed_prompts))
-    if world > 1:
+    if use_pg:
         tt = torch.tensor([dt], device="cpu" if rehearsal else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -356,12 +359,14 @@ def main() -> None:
         result["cpu_baseline"], refs = cpu_baseline(cfg, timed_prompts[:9], NEW_TOKENS)
         result["parity"] = parity_vs_oracle(model, timed_prompts, [o for out in outs for o in out], refs, gen_kw)
     if rank == 0:
+        if use_pg:
+            result["config"]["process_group"] = dist.get_backend()
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 
-def bench_finetune(a, wl, cfg, model, dev, rank: int, world: int, rehearsal: bool) -> None:
+def bench_finetune(a, wl, cfg, model, dev, rank: int, world: int, rehearsal: bool, use_pg: bool = False) -> None:
     """BASELINE configs[2]: data-parallel LoRA fine-tune.  A step = ONE optimizer step over a global batch of 32
     utterances (finetune/ger.py:381: batch_size 32, micro_batch_size 1): every rank runs 32 / world micro-steps
     (GraphedTrainStep: forward + chunked CE + backward as one hipGraph replay, gradients accumulated into the flat fp32
@@ -394,7 +399,7 @@ def bench_finetune(a, wl, cfg, model, dev, rank: int, world: int, rehearsal: boo
     labs = [labs_all[g * PACK:(g + 1) * PACK].contiguous() for g in range(n_groups)]
 
     def barrier():
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -416,7 +421,7 @@ def bench_finetune(a, wl, cfg, model, dev, rank: int, world: int, rehearsal: boo
     barrier()
     dt = time.perf_counter() - t0
     mean_loss = last.mean().to(torch.float64)
-    if world > 1:
+    if use_pg:
         tt = torch.tensor([dt], device="cpu" if rehearsal else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -439,12 +444,13 @@ def bench_finetune(a, wl, cfg, model, dev, rank: int, world: int, rehearsal: boo
             "data": "synthetic",
             "config": {"workload": wl["what"], "global_batch": GLOBAL, "micro_batches_per_rank_per_step": per_rank, "tokens": T,
                        "micro_batches_per_packed_launch": PACK,
-                       "parallelism": f"data-parallel x{world}, flat LoRA-gradient bucket of {bucket.flat.numel()} fp32 elements"},
+                       "parallelism": f"data-parallel x{world}, flat LoRA-gradient bucket of {bucket.flat.numel()} fp32 elements",
+                       **({"process_group": dist.get_backend()} if use_pg else {})},
             "roofline": {"bound": "mfma", "kernel": wl["kernel"], "achieved": achieved, "peak": wl["peak"], "unit": "TFLOP/s",
                          "frac": achieved / wl["peak"], "traffic": None, "flop_per_utterance": flop_utt,
                          "note": "algorithmic FLOP of the whole micro-step / wall time per GPU: kernels inside a hipGraph replay cannot be bracketed by events"},
             "last_loss": float(last.mean().item()), "mean_loss_last_step": float(mean_loss.item()), "cpu_baseline": None}), flush=True)
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 

@@ -84,7 +84,7 @@ class FlatGradBucket:
 
     def all_reduce_mean(self) -> None:
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_available() and dist.is_initialized():        # also with one rank under a launcher: the collective still runs
             if dist.get_backend() == "gloo" and self.flat.is_cuda:      # rehearsal on one GPU: stage through the host
                 host = self.flat.cpu()
                 dist.all_reduce(host, op=dist.ReduceOp.SUM)
