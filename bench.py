@@ -91,6 +91,19 @@ def decode_bytes_per_step(cfg, rows: float, mean_ctx: float, weight_bytes: int, 
     return float(weights + rows * kv * mean_ctx)
 
 
+_RESULT_FD = None
+
+
+def emit(result: dict) -> None:
+    """the bench's one line, on the process's ORIGINAL stdout"""
+    line = (json.dumps(result) + "\n").encode()
+    sys.stdout.flush()
+    if _RESULT_FD is None:
+        os.write(1, line)
+    else:
+        os.write(_RESULT_FD, line)
+
+
 def launch_cmd(n: int, argv: list) -> list:
     """The command the driver itself uses for N > 1: torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1."""
     with socket.socket() as sk:
@@ -154,6 +167,12 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if a.selftest_launch:
         return selftest_launch(a, world)
+    # ONE JSON line on stdout, whatever the libraries print (RCCL writes a five-line version banner to stdout when its first
+    # communicator comes up): file descriptor 1 is pointed at stderr for the whole run and the result line goes to the saved one
+    global _RESULT_FD
+    sys.stdout.flush()
+    _RESULT_FD = os.dup(1)
+    os.dup2(2, 1)
     wl = WORKLOADS[a.config]
     PROMPT_LEN = wl["prompt"]
     if a.in_flight is None:
@@ -361,7 +380,7 @@ def main() -> None:
     if rank == 0:
         if use_pg:
             result["config"]["process_group"] = dist.get_backend()
-        print(json.dumps(result), flush=True)
+        emit(result)
     if use_pg:
         dist.destroy_process_group()
 
@@ -438,7 +457,7 @@ def bench_finetune(a, wl, cfg, model, dev, rank: int, world: int, rehearsal: boo
         flop_utt = 4.0 * n_lin * T + 6.0 * n_lora * T + attn
         utt = GLOBAL * a.steps
         achieved = flop_utt * utt / dt / 1e12 / world          # per GPU
-        print(json.dumps({
+        emit({
             "metric": wl["metric"], "value": utt / dt, "unit": "utterances/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": wl["dtype"],
             "data": "synthetic",
@@ -449,7 +468,7 @@ def bench_finetune(a, wl, cfg, model, dev, rank: int, world: int, rehearsal: boo
             "roofline": {"bound": "mfma", "kernel": wl["kernel"], "achieved": achieved, "peak": wl["peak"], "unit": "TFLOP/s",
                          "frac": achieved / wl["peak"], "traffic": None, "flop_per_utterance": flop_utt,
                          "note": "algorithmic FLOP of the whole micro-step / wall time per GPU: kernels inside a hipGraph replay cannot be bracketed by events"},
-            "last_loss": float(last.mean().item()), "mean_loss_last_step": float(mean_loss.item()), "cpu_baseline": None}), flush=True)
+            "last_loss": float(last.mean().item()), "mean_loss_last_step": float(mean_loss.item()), "cpu_baseline": None})
     if use_pg:
         dist.destroy_process_group()
 
