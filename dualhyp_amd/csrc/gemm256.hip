@@ -16,6 +16,7 @@
 //   MFMA  : 16x16x32 (higher sustained clock than 32x32x16 on gfx950, MI355X_MICROARCH DVFS item 7)
 // Epilogues as in gemm.hip; the LoRA rank-16 update is one zero-padded K=32 MFMA per 16 x 16 tile.
 #include <type_traits>
+#include <utility>
 
 #include "common.h"
 #include "gemm.h"
@@ -36,38 +37,28 @@ extern "C" int dh_debug_g256_stamps(unsigned long long* out) {
 #define G256_STAMP(i)
 #endif
 
-template <int EPI, bool RESID, int PIPE>
-__global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    G256_STAMP(0);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wn = wave >> 2, wm = wave & 3;
-    const int frow = lane & 15, kg = lane >> 4;
-
+// tiles are walked in bands of `gm` m-tiles, m fastest: the ~32 blocks an XCD runs at a time then form a
+// gm x (32/gm) rectangle that shares gm x-tile streams and 32/gm W-tile streams through its L2
+// instead of 1 + 32 (row-major); a.gm = 1 is the row-major order
+template <int EPI>
+__device__ __forceinline__ void g256_tile_origin(const GemmArgs& a, const int bid, int& m0, int& n0) {
     const int nwg = a.nb_n * a.nb_m;
-    // tiles are walked in bands of `gm` m-tiles, m fastest: the ~32 blocks an XCD runs at a time then form a
-    // gm x (32/gm) rectangle that shares gm x-tile streams and 32/gm W-tile streams through its L2
-    // instead of 1 + 32 (row-major); a.gm = 1 is the row-major order
-    auto tile_origin = [&](int bid, int& m0, int& n0) __attribute__((always_inline)) {
-        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-        const int gm = a.gm, band = tile / (gm * a.nb_n), within = tile - band * (gm * a.nb_n);
-        const int rows = min(gm, a.nb_m - band * gm);
-        const int tm = band * gm + within % rows, tn = within / rows;
-        m0 = tm * BT2;
-        n0 = (EPI == DH_EPI_SWIGLU) ? tn * 128 : tn * BT2;
-    };
-    int m0, n0;
-    tile_origin(blockIdx.x, m0, n0);
-    // PIPE 3: PERSISTENT ping-pong — the grid is one block per CU and a block walks tiles bid, bid + grid, ...; the first
-    // three stages of the NEXT tile are requested before the epilogue of the current one, so the epilogue (2.8-10.8 us),
-    // the store drain, the block dispatch and the first-stage latency (2 us) of tools/probe_gemm256.py's timeline overlap
-    constexpr bool PERSIST = PIPE == 3;
-    constexpr int LOOP = PIPE == 3 ? 2 : PIPE;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int gm = a.gm, band = tile / (gm * a.nb_n), within = tile - band * (gm * a.nb_n);
+    const int rows = min(gm, a.nb_m - band * gm);
+    const int tm = band * gm + within % rows, tn = within / rows;
+    m0 = tm * BT2;
+    n0 = (EPI == DH_EPI_SWIGLU) ? tn * 128 : tn * BT2;
+}
 
-    f32x4 acc[8][4];
-    auto epilogue = [&](const int m0, const int n0) __attribute__((always_inline)) {
-    G256_STAMP(2);
+// The epilogue of a wave that owns 128 (n) x 16 MJ (m) of the block tile: acc[i][j] is the 16 x 16 tile of column tile i, row
+// strip j.  MJ = 4: the 8-wave kernel (waves 2 x 4), MJ = 8: the 4-wave kernel (waves 2 x 2).
+template <int EPI, bool RESID, int MJ>
+__device__ __forceinline__ void g256_epilogue(const GemmArgs& a, f32x4 (&acc)[8][MJ], const int m0, const int n0, const int wn,
+                                              const int wm, const int lane) {
+    const int frow = lane & 15, kg = lane >> 4;
+    const int mw0 = m0 + wm * (MJ * 16);
     // ---------------------------------------------------------------- epilogue
     // acc[i][j][r]: n = nt + 4*kg + r , m = mt + frow: a lane holds 4 consecutive n (8 bytes of bf16) of one
     // row; the four kg lanes of a row hold one 16-column tile.  Tiles are finished in PAIRS and one
@@ -100,7 +91,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
     bf16x8 xfv2[2][LORA ? NT / 2 : 1];
     uint4 rrv2[2][RESID ? NT / 2 : 1];
     auto load_strip = [&](int j, bf16x8 (&xf)[LORA ? NT / 2 : 1], uint4 (&rr)[RESID ? NT / 2 : 1]) __attribute__((always_inline)) {
-        const int m = m0 + wm * 64 + j * 16 + frow;
+        const int m = mw0 + j * 16 + frow;
         const bool m_ok = m < a.M;
         if (LORA && a.lora_b != nullptr) {
             const int mm = m_ok ? m : a.M - 1;
@@ -125,11 +116,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
     };
     // fused-QKV epilogue: the token positions / cache slots of all four row strips up front (the rope tables are
     // indexed by them: one dependent round trip per strip less)
-    int posv[EPI == DH_EPI_QKV ? 4 : 1], slotv[EPI == DH_EPI_QKV ? 4 : 1];
+    int posv[EPI == DH_EPI_QKV ? MJ : 1], slotv[EPI == DH_EPI_QKV ? MJ : 1];
     if constexpr (EPI == DH_EPI_QKV) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int mm = m0 + wm * 64 + j * 16 + frow;
+        for (int j = 0; j < MJ; ++j) {
+            int mm = mw0 + j * 16 + frow;
             mm = mm < a.M ? mm : a.M - 1;
             posv[j] = a.tok_pos[mm];
             slotv[j] = a.tok_slot[mm];
@@ -137,10 +128,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
     }
     load_strip(0, xfv2[0], rrv2[0]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + wm * 64 + j * 16 + frow;
+    for (int j = 0; j < MJ; ++j) {
+        const int m = mw0 + j * 16 + frow;
         const bool m_ok = m < a.M;
-        if (j + 1 < 4) load_strip(j + 1, xfv2[(j + 1) & 1], rrv2[(j + 1) & 1]);
+        if (j + 1 < MJ) load_strip(j + 1, xfv2[(j + 1) & 1], rrv2[(j + 1) & 1]);
         bf16x8 (&xfv)[LORA ? NT / 2 : 1] = xfv2[j & 1];
         uint4 (&rrv)[RESID ? NT / 2 : 1] = rrv2[j & 1];
         if constexpr (EPI == DH_EPI_QKV) {
@@ -311,7 +302,31 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
             }
         }
     }
-    G256_STAMP(3);
+}
+
+template <int EPI, bool RESID, int PIPE>
+__global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    G256_STAMP(0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 2, wm = wave & 3;
+    const int frow = lane & 15, kg = lane >> 4;
+
+    const int nwg = a.nb_n * a.nb_m;
+    auto tile_origin = [&](int bid, int& m0, int& n0) __attribute__((always_inline)) { g256_tile_origin<EPI>(a, bid, m0, n0); };
+    int m0, n0;
+    tile_origin(blockIdx.x, m0, n0);
+    // PIPE 3: PERSISTENT ping-pong — the grid is one block per CU and a block walks tiles bid, bid + grid, ...; the first
+    // three stages of the NEXT tile are requested before the epilogue of the current one, so the epilogue (2.8-10.8 us),
+    // the store drain, the block dispatch and the first-stage latency (2 us) of tools/probe_gemm256.py's timeline overlap
+    constexpr bool PERSIST = PIPE == 3;
+    constexpr int LOOP = PIPE == 3 ? 2 : PIPE;
+
+    f32x4 acc[8][4];
+    auto epilogue = [&](const int m0, const int n0) __attribute__((always_inline)) {
+        G256_STAMP(2);
+        g256_epilogue<EPI, RESID, 4>(a, acc, m0, n0, wn, wm, lane);
+        G256_STAMP(3);
     };
     auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -560,6 +575,171 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
     }
 }
 
+// ---- four waves, one per SIMD, 128 (n) x 128 (m) per wave, operands fetched in FULL 128-byte lines -------------------------
+// What the 8-wave kernel above leaves on the table (tools/gemm_yardstick.py, tools/pmc_gemm_ta.py: the vendor library's
+// hand-written 256 x 256 x 64 kernel runs the K = 2048 / 5632 shapes of the prefill 1.2-1.3x faster):
+//   * its 32-deep stages are rows of 64 B, i.e. every 128-B line of W and x is requested twice, half a line at a time:
+//     TCP_TCC_READ_REQ 46.0 M against the library's 23.1 M for the same bytes, TA_ADDR_STALLED_BY_TC 2.3x.  Here a stage is 64
+//     deep: one LDS-DMA instruction moves 8 rows x 128 B (whole lines) into a [row][128 B] image, XOR-swizzled on the
+//     SOURCE side ((row >> 1) & 7, the ds_read_b128 lane groups of MI355X_MICROARCH.md) so fragment reads are conflict-free;
+//   * a wave that owns 128 x 128 feeds 64 MFMAs per 32-deep k-step from 16 ds_read_b128 (128 KiB of LDS reads per 64-deep
+//     stage instead of 192), and with one wave per SIMD the accumulators live in the AGPR half of the 512-register file.
+// LDS: two stages of (W 32 KiB + x 32 KiB).  Registers hold BOTH k-steps of the current stage (F0, F1: 2 x 16 fragments), so
+// a stage's buffer is free again half way through its own iteration:
+//   phase A: 64 MFMAs on F0 | 16 reads F1 <- stage s (second k-step) | lgkmcnt(0), barrier B1: buffer s&1 is free
+//            | 16 DMA pieces of stage s+2 -> buffer s&1 ...
+//   phase B: ... | 64 MFMAs on F1 | vmcnt(16), barrier B2: stage s+1 has landed | 16 reads F0 <- stage s+1 (first k-step)
+// A DMA piece has ~1.4 iterations to land.  The MFMAs are asm volatile with the accumulator pinned ("+a" for 56 tiles, "+v"
+// for 8): with the builtin the register allocator keeps some accumulators in VGPRs and shuttles them through
+// v_accvgpr_write / _read around every use (~230 moves per k-step); with all 64 in AGPRs it has no AGPR left for its own
+// copies and does the same.  Memory operations do not cross a volatile asm, so the interleave in the source is the one issued.
+// DMA pieces use the saddr form of global_load_lds (uniform base + one 32-bit VGPR offset per piece): no 64-bit VALU address
+// arithmetic between the MFMAs.  (buffer_load ... lds through __builtin_amdgcn_raw_ptr_buffer_load_lds is not usable from
+// C++: the compiler then puts s_waitcnt vmcnt(0) in front of every ds_read that may alias the DMA's LDS destination.)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+// DMA piece d (0..15) goes out 2 d + d / 2 slots after the first one (one piece per 2-3 MFMAs, the last at +37): the piece
+// issued at offset o, or -1
+constexpr int dma_at(int o) {
+    for (int d = 0; d < 16; ++d)
+        if (2 * d + d / 2 == o) return d;
+    return -1;
+}
+
+template <int EPI, bool RESID>
+__global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wm = wave & 1;
+    const int frow = lane & 15, kg = lane >> 4;
+    int m0, n0;
+    g256_tile_origin<EPI>(a, blockIdx.x, m0, n0);
+
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int BUF = 2 * TILE_B, OPB = TILE_B;    // bytes per stage / per operand of a stage (256 rows x 128 B)
+    // ---- DMA sources: wave w moves row groups R = 8 w .. 8 w + 7 (8 rows x 128 B each) of W and of x
+    uint32_t voA[8], voB[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int R = wave * 8 + j;
+        const int row = R * 8 + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        int n;
+        if (EPI == DH_EPI_SWIGLU) n = n0 + (row >> 7) * 64 + (row & 63);   // wave-row half wn: 64 rows of fc_1, then the same 64 of fc_2
+        else n = n0 + row;
+        n = n < a.N ? n : a.N - 1;
+        voA[j] = ((uint32_t)n * (uint32_t)a.K + chunk * 8) * 2;
+        int m = m0 + row;
+        m = m < a.M ? m : a.M - 1;
+        voB[j] = ((uint32_t)m * (uint32_t)a.K + chunk * 8) * 2;
+    }
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto dma = [&](int d, int st, int b) __attribute__((always_inline)) {      // piece d (0..15: A0 B0 A1 B1 ...) of stage st -> buffer b
+        const int j = d >> 1, R = wave_u * 8 + j;
+        char* dst = smem + b * BUF + R * 1024;
+        // uniform base + 32-bit lane offset: the saddr form of global_load_lds (no 64-bit VALU address arithmetic)
+        // the saddr form (uniform base in an SGPR pair + one 32-bit lane offset), written out: from the builtin the compiler
+        // hoists the zero-extended lane offsets out of the loop as 64-bit VGPR pairs and issues v_lshl_add_u64 + the
+        // 64-bit-address form per piece
+        auto issue = [&](const char* base, uint32_t vo, char* lds_dst) __attribute__((always_inline)) {
+            const uint32_t lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_dst;
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(base), "s"(lds) : "memory", "m0");
+        };
+        if (d & 1) {
+            issue(reinterpret_cast<const char*>(a.x) + (size_t)st * 128, voB[j], dst + OPB);
+        } else {
+            // rows 64..127 of a wave-row half: fc_2 (R & 8 == wave & 1)
+            issue(reinterpret_cast<const char*>((EPI == DH_EPI_SWIGLU && (R & 8)) ? a.w2 : a.w) + (size_t)st * 128, voA[j], dst);
+        }
+    };
+    // ---- fragment reads: row r of an operand image at r * 128, its 16-B piece c at position c ^ ((r >> 1) & 7)
+    const int sw = (frow >> 1) & 7;
+    const int offA = (wn * 128 + frow) * 128, offB = OPB + (wm * 128 + frow) * 128;
+    const int co[2] = {(kg ^ sw) << 4, ((4 + kg) ^ sw) << 4};
+    auto rd = [&](int r, int b, int ks, bf16x8 (&fa)[8], bf16x8 (&fb)[8]) __attribute__((always_inline)) {   // read r: 0..15 = b0 a0 b1 a1 ...
+        const char* base = smem + b * BUF + co[ks];
+        if (r & 1) fa[r >> 1] = *reinterpret_cast<const bf16x8*>(base + offA + (r >> 1) * 2048);
+        else fb[r >> 1] = *reinterpret_cast<const bf16x8*>(base + offB + (r >> 1) * 2048);
+    };
+    auto mfma = [&](int t, const bf16x8 (&fa)[8], const bf16x8 (&fb)[8]) __attribute__((always_inline)) {
+        const int i = t >> 3, j = t & 7;
+        if (i < 7) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(fa[i]), "v"(fb[j]));
+        else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(fa[i]), "v"(fb[j]));
+    };
+    const int nst = a.K / 64;                         // >= 2 (dh_linear_256 checks)
+    bf16x8 fa0[8], fb0[8], fa1[8], fb1[8];
+    // slots 0..127 of an iteration: MFMA t of phase A is slot t, of phase B slot 64 + t
+    constexpr int B1_SLOT = 36, DMA_SLOT0 = 38, B2_SLOT = 64 + 16, RD0_SLOT = 64 + 17;
+    auto iteration = [&](auto pre_c, auto nxt_c, int st) __attribute__((always_inline)) {
+        constexpr bool PRE = decltype(pre_c)::value, NXT = decltype(nxt_c)::value;
+        const int b = st & 1;
+        static_for<128>([&](auto gc) __attribute__((always_inline)) {
+            constexpr int g = decltype(gc)::value;
+            if constexpr (g < 64) mfma(g, fa0, fb0);
+            else mfma(g - 64, fa1, fb1);
+            if constexpr (g < 32 && (g & 1)) rd(g >> 1, b, 1, fa1, fb1);
+            if constexpr (PRE && g == B1_SLOT) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            if constexpr (PRE && g >= DMA_SLOT0 && dma_at(g - DMA_SLOT0) >= 0) dma(dma_at(g - DMA_SLOT0), st + 2, b);
+            if constexpr (NXT && g == B2_SLOT) {
+                if (PRE) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            if constexpr (NXT && g >= RD0_SLOT && g < RD0_SLOT + 32 && ((g - RD0_SLOT) & 1) == 0) rd((g - RD0_SLOT) >> 1, b ^ 1, 0, fa0, fb0);
+        });
+    };
+    constexpr std::true_type T{};
+    constexpr std::false_type F{};
+#pragma unroll
+    for (int d = 0; d < 16; ++d) dma(d, 0, 0);
+#pragma unroll
+    for (int d = 0; d < 16; ++d) dma(d, 1, 1);
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rd(r, 0, 0, fa0, fb0);
+    int st = 0;
+    for (; st + 2 < nst; ++st) iteration(T, T, st);
+    iteration(F, T, st);
+    iteration(F, F, st + 1);
+    // The compiler has no hazard model for an MFMA inside an asm: it would start the epilogue's v_accvgpr_read of a tile right
+    // behind that tile's last MFMA.  Wait the matrix pipe out, then tie every accumulator to an (empty) volatile asm behind the
+    // wait: volatile asms keep their order, and the epilogue's reads now depend on the later one.
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (i < 7) asm volatile("" : "+a"(acc[i][j]));
+            else asm volatile("" : "+v"(acc[i][j]));
+        }
+    g256_epilogue<EPI, RESID, 8>(a, acc, m0, n0, wn, wm, lane);
+}
+
+// two 64-deep stages at least; operands addressed through 32-bit buffer offsets
+inline bool w4_ok(const GemmArgs& a) {
+    return a.K >= 128 && (size_t)a.N * a.K * 2 < (1ull << 32) && (size_t)a.M * a.K * 2 < (1ull << 32);
+}
+
+template <int EPI, bool RESID>
+int launch_w4(const GemmArgs& a, hipStream_t s) {
+    auto kfn = gemm_nt256w4_kernel<EPI, RESID>;
+    DH_MAX_LDS_ONCE(kfn, 4 * TILE_B);
+    hipLaunchKernelGGL(kfn, dim3(a.nb_n * a.nb_m), dim3(256), 4 * TILE_B, s, a);
+    DH_LAUNCH_CHECK();
+    return 0;
+}
+
 template <int EPI, bool RESID, int PIPE>
 int launch_one(const GemmArgs& a, hipStream_t s) {
     auto kfn = gemm_nt256_kernel<EPI, RESID, PIPE>;
@@ -585,6 +765,7 @@ template <int EPI>
 int launch(const GemmArgs& a, hipStream_t s) {
     // 1: ping-pong (default), 2: 4-stage pipeline with both waves of a SIMD in phase, 3: BK = 64 double buffer
     // 4: persistent ping-pong where its loop-carried state fits the registers (the LoRA epilogues spill 47-116 VGPRs)
+    if (g_gemm_variant == 5 && w4_ok(a)) return a.resid ? launch_w4<EPI, true>(a, s) : launch_w4<EPI, false>(a, s);
     if (g_gemm_variant == 4 && (EPI == DH_EPI_PLAIN || EPI == DH_EPI_SWIGLU))
         return a.resid ? launch_one<EPI, true, 3>(a, s) : launch_one<EPI, false, 3>(a, s);
     if (g_gemm_variant == 3) return a.resid ? launch_one<EPI, true, 0>(a, s) : launch_one<EPI, false, 0>(a, s);
@@ -606,7 +787,7 @@ int dh_linear_256(GemmArgs a, int epilogue, hipStream_t s) {
         case DH_EPI_LORA: return launch<DH_EPI_LORA>(a, s);
         case DH_EPI_SWIGLU: return launch<DH_EPI_SWIGLU>(a, s);
         case DH_EPI_ADAPTER: return launch<DH_EPI_ADAPTER>(a, s);
-        case DH_EPI_QKV: return launch_one<DH_EPI_QKV, false, 2>(a, s);
+        case DH_EPI_QKV: return g_gemm_variant == 5 && w4_ok(a) ? launch_w4<DH_EPI_QKV, false>(a, s) : launch_one<DH_EPI_QKV, false, 2>(a, s);
     }
     dh_set_error("dh_linear_bf16: unknown epilogue %d", epilogue);
     return 1;
