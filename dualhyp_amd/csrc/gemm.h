@@ -61,7 +61,7 @@ bool dh_linear_is_big(int M, int N, int epilogue);
 int dh_linear_256(GemmArgs a, int epilogue, hipStream_t s);
 extern int g_linear_phase;
 extern int g_gemm_gm;
-extern int g_gemm_variant;   // 0: always the 128-tile kernel; 1 / 2 / 3: 256-tile kernel, loop variants of gemm256.hip; 4 (default): 1 with persistent blocks for the PLAIN / SwiGLU epilogues
+extern int g_gemm_variant;   // 0: always the 128-tile kernel; 1 / 2 / 3: 256-tile kernel, loop variants of gemm256.hip; 4: 1 with persistent blocks for the PLAIN / SwiGLU epilogues; 5 (default): the 4-wave full-line kernel
 
 // dh_linear_bf16 with an explicit kernel choice.  kernel: 0 = by shape (M <= 32 -> streaming),
 // 1 = tiled MFMA kernel whatever M, 2 = decode phase (streaming kernels up to 256 rows).  The engine pins the choice per PHASE (prefill = tiled,

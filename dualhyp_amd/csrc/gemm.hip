@@ -245,7 +245,7 @@ int launch(const GemmArgs& a, hipStream_t s) {
 
 }  // namespace
 
-int g_gemm_variant = 4;
+int g_gemm_variant = 5;
 int g_linear_phase = 0;   // kernel choice of the public dh_linear_bf16 (dh_set_tuning key 4; tools and tests)
 
 extern "C" int dh_linear_bf16(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N, int K, int epilogue,

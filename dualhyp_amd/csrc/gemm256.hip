@@ -52,6 +52,12 @@ __device__ __forceinline__ void g256_tile_origin(const GemmArgs& a, const int bi
     n0 = (EPI == DH_EPI_SWIGLU) ? tn * 128 : tn * BT2;
 }
 
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>) (#pragma unroll gives up on the big bodies below,
+// and a loop that stays a loop indexes the accumulator array dynamically, i.e. puts it in scratch)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 // The epilogue of a wave that owns 128 (n) x 16 MJ (m) of the block tile: acc[i][j] is the 16 x 16 tile of column tile i, row
 // strip j.  MJ = 4: the 8-wave kernel (waves 2 x 4), MJ = 8: the 4-wave kernel (waves 2 x 2).
 template <int EPI, bool RESID, int MJ>
@@ -127,8 +133,8 @@ __device__ __forceinline__ void g256_epilogue(const GemmArgs& a, f32x4 (&acc)[8]
         }
     }
     load_strip(0, xfv2[0], rrv2[0]);
-#pragma unroll
-    for (int j = 0; j < MJ; ++j) {
+    static_for<MJ>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
         const int m = mw0 + j * 16 + frow;
         const bool m_ok = m < a.M;
         if (j + 1 < MJ) load_strip(j + 1, xfv2[(j + 1) & 1], rrv2[(j + 1) & 1]);
@@ -229,7 +235,7 @@ __device__ __forceinline__ void g256_epilogue(const GemmArgs& a, f32x4 (&acc)[8]
                     head(std::integral_constant<int, 128>{}, 0);
                 }
             }
-            continue;
+            return;
         }
         // packed bf16 x4 of output tile i for this lane (all lanes run it: the swap below is wave-wide)
         auto tile_value = [&](int i) __attribute__((always_inline)) -> uint2 {
@@ -301,7 +307,7 @@ __device__ __forceinline__ void g256_epilogue(const GemmArgs& a, f32x4 (&acc)[8]
                 if (m_ok && na + 16 < a.N) *reinterpret_cast<uint2*>(a.y + (size_t)m * a.N + na + 16) = with_resid(tb, na + 16);
             }
         }
-    }
+    });
 }
 
 template <int EPI, bool RESID, int PIPE>
@@ -596,17 +602,42 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
 // DMA pieces use the saddr form of global_load_lds (uniform base + one 32-bit VGPR offset per piece): no 64-bit VALU address
 // arithmetic between the MFMAs.  (buffer_load ... lds through __builtin_amdgcn_raw_ptr_buffer_load_lds is not usable from
 // C++: the compiler then puts s_waitcnt vmcnt(0) in front of every ds_read that may alias the DMA's LDS destination.)
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
-// DMA piece d (0..15) goes out 2 d + d / 2 slots after the first one (one piece per 2-3 MFMAs, the last at +37): the piece
-// issued at offset o, or -1
-constexpr int dma_at(int o) {
+// ---- the 4-wave kernel's schedule: slots 0..127 of an iteration (MFMA t of phase A is slot t, of phase B slot 64 + t)
+#ifndef DH_W4_RD1STEP
+#define DH_W4_RD1STEP 2      // a read of F1 behind every RD1STEP-th MFMA from slot 0
+#endif
+#ifndef DH_W4_B1
+#define DH_W4_B1 36          // barrier B1 (buffer s&1 free) behind this slot
+#endif
+#ifndef DH_W4_DMA0
+#define DH_W4_DMA0 38        // first DMA piece of stage s+2
+#endif
+#ifndef DH_W4_DMANUM
+#define DH_W4_DMANUM 5       // piece d goes out d * NUM / DEN slots later (a piece per 4-6 MFMAs: +7 % over one per 2-3,
+#define DH_W4_DMADEN 1       //  profiles/r03_sweep_w4_*.txt — its issue takes the wave tens of cycles, MI355X_MICROARCH.md)
+#endif
+#ifndef DH_W4_B2
+#define DH_W4_B2 80          // barrier B2 (stage s+1 landed) behind this slot
+#endif
+#ifndef DH_W4_RD0
+#define DH_W4_RD0 81         // first read of the next stage's F0
+#endif
+#ifndef DH_W4_RD0STEP
+#define DH_W4_RD0STEP 2
+#endif
+constexpr int w4_dma_slot(int d) { return DH_W4_DMA0 + d * DH_W4_DMANUM / DH_W4_DMADEN; }
+constexpr int w4_dma_at(int g) {             // the piece issued behind slot g, or -1
     for (int d = 0; d < 16; ++d)
-        if (2 * d + d / 2 == o) return d;
+        if (w4_dma_slot(d) == g) return d;
     return -1;
 }
+constexpr int w4_dma_before(int g) {         // pieces issued behind slots <= g
+    int n = 0;
+    for (int d = 0; d < 16; ++d) n += w4_dma_slot(d) <= g;
+    return n;
+}
+static_assert(w4_dma_slot(15) < 128 && DH_W4_B1 < DH_W4_DMA0 && 15 * DH_W4_RD1STEP < DH_W4_B1, "B1 behind the last F1 read, in front of the first piece");
+static_assert(DH_W4_RD0 > DH_W4_B2 && DH_W4_RD0 + 15 * DH_W4_RD0STEP < 128, "F0 reads behind B2");
 
 template <int EPI, bool RESID>
 __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
@@ -675,8 +706,6 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
     };
     const int nst = a.K / 64;                         // >= 2 (dh_linear_256 checks)
     bf16x8 fa0[8], fb0[8], fa1[8], fb1[8];
-    // slots 0..127 of an iteration: MFMA t of phase A is slot t, of phase B slot 64 + t
-    constexpr int B1_SLOT = 36, DMA_SLOT0 = 38, B2_SLOT = 64 + 16, RD0_SLOT = 64 + 17;
     auto iteration = [&](auto pre_c, auto nxt_c, int st) __attribute__((always_inline)) {
         constexpr bool PRE = decltype(pre_c)::value, NXT = decltype(nxt_c)::value;
         const int b = st & 1;
@@ -684,18 +713,20 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
             constexpr int g = decltype(gc)::value;
             if constexpr (g < 64) mfma(g, fa0, fb0);
             else mfma(g - 64, fa1, fb1);
-            if constexpr (g < 32 && (g & 1)) rd(g >> 1, b, 1, fa1, fb1);
-            if constexpr (PRE && g == B1_SLOT) {
+            if constexpr (g % DH_W4_RD1STEP == DH_W4_RD1STEP - 1 && g / DH_W4_RD1STEP < 16) rd(g / DH_W4_RD1STEP, b, 1, fa1, fb1);
+            if constexpr (PRE && g == DH_W4_B1) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
-            if constexpr (PRE && g >= DMA_SLOT0 && dma_at(g - DMA_SLOT0) >= 0) dma(dma_at(g - DMA_SLOT0), st + 2, b);
-            if constexpr (NXT && g == B2_SLOT) {
-                if (PRE) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            if constexpr (PRE && w4_dma_at(g) >= 0) dma(w4_dma_at(g), st + 2, b);
+            if constexpr (NXT && g == DH_W4_B2) {
+                // the pieces of stage s+2 issued so far stay in flight; everything older (stage s+1) has landed
+                if constexpr (PRE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(w4_dma_before(DH_W4_B2)) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
-            if constexpr (NXT && g >= RD0_SLOT && g < RD0_SLOT + 32 && ((g - RD0_SLOT) & 1) == 0) rd((g - RD0_SLOT) >> 1, b ^ 1, 0, fa0, fb0);
+            if constexpr (NXT && g >= DH_W4_RD0 && (g - DH_W4_RD0) % DH_W4_RD0STEP == 0 && (g - DH_W4_RD0) / DH_W4_RD0STEP < 16)
+                rd((g - DH_W4_RD0) / DH_W4_RD0STEP, b ^ 1, 0, fa0, fb0);
         });
     };
     constexpr std::true_type T{};

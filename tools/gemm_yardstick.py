@@ -32,18 +32,18 @@ shapes = [("QKV", 16384, 2560, 2048), ("proj", 16384, 2048, 2048), ("fc (one hal
           ("fc both halves", 16384, 11264, 2048), ("mlp proj", 16384, 2048, 5632), ("lm_head", 640, 32000, 2048),
           ("decode QKV", 640, 2560, 2048), ("decode proj", 640, 2048, 2048), ("decode fc both", 640, 11264, 2048),
           ("decode mlp proj", 640, 2048, 5632), ("square 8192", 8192, 8192, 8192)]
-print(f"{'shape':28s} {'M':>6s} {'N':>6s} {'K':>6s} | {'torch us':>9s} {'TFLOP/s':>8s} | {'ours us':>9s} {'TFLOP/s':>8s} | {'4-wave us':>9s} {'TFLOP/s':>8s} | torch/ours torch/4-wave")
+print(f"{'shape':28s} {'M':>6s} {'N':>6s} {'K':>6s} | {'torch us':>9s} {'TFLOP/s':>8s} | {'8-wave us':>9s} {'TFLOP/s':>8s} | {'4-wave us':>9s} {'TFLOP/s':>8s} | torch/ours torch/4-wave")
 for nm, M, N, K in shapes:
     x, w = rn(M, K), rn(N, K)
     y = torch.empty(M, N, device=D, dtype=torch.bfloat16)
     reps = 30 if M >= 8192 else 200
     t_lib = timed(lambda: torch.matmul(x, w.t(), out=y), reps)
+    lib.dh_set_tuning(1, 4)                    # the 8-wave kernel (the default until round 3)
     t_own = timed(lambda: ops.linear(x, w, out=y), reps)
     y_own = ops.linear(x, w)
-    lib.dh_set_tuning(1, 5)                    # the 4-wave 128 x 128-per-wave kernel
+    lib.dh_set_tuning(1, 5)                    # the 4-wave 128 x 128-per-wave full-line kernel (default)
     t_w4 = timed(lambda: ops.linear(x, w, out=y), reps)
     y_w4 = ops.linear(x, w)
-    lib.dh_set_tuning(1, 4)
     fl = 2.0 * M * N * K
     print(f"{nm:28s} {M:6d} {N:6d} {K:6d} | {t_lib:9.1f} {fl / t_lib * 1e-6:8.0f} | {t_own:9.1f} {fl / t_own * 1e-6:8.0f} | {t_w4:9.1f} {fl / t_w4 * 1e-6:8.0f} | "
           f"{t_lib / t_own:5.2f}x {t_lib / t_w4:5.2f}x  bit-equal {bool(torch.equal(y_own, y_w4))}", flush=True)

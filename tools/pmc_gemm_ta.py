@@ -28,7 +28,7 @@ x, w = rn(M, K), rn(N, K)
 y = torch.empty(M, N, device=D, dtype=torch.bfloat16)
 for _ in range(3):
     torch.matmul(x, w.t(), out=y)
-for v in (2, 5):
+for v in (2, 5):   # 8-wave ping-pong, 4-wave full-line
     lib.dh_set_tuning(1, v)
     for _ in range(3):
         ops.linear(x, w, out=y)
