@@ -21,6 +21,8 @@
 #include "common.h"
 #include "gemm.h"
 
+int g_w4_persist = 1;   // dh_set_tuning(22, 0 | 1 | 2): the 4-wave kernel walks the tiles with one block per CU: never / where the epilogue loads nothing / always
+
 namespace {
 
 constexpr int BT2 = 256;
@@ -60,7 +62,10 @@ template <int N, class F>
 __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 // The epilogue of a wave that owns 128 (n) x 16 MJ (m) of the block tile: acc[i][j] is the 16 x 16 tile of column tile i, row
 // strip j.  MJ = 4: the 8-wave kernel (waves 2 x 4), MJ = 8: the 4-wave kernel (waves 2 x 2).
-template <int EPI, bool RESID, int MJ>
+// FULL: the block tile lies inside the matrix — every bound below is then known at compile time, the epilogue has no exec-mask
+// branches, and (what matters) the compiler can COUNT its loads: with predicated loads inside branches it waits vmcnt(0) before
+// the first store, i.e. for the operands of every strip requested ahead.
+template <int EPI, bool RESID, int MJ, bool FULL>
 __device__ __forceinline__ void g256_epilogue(const GemmArgs& a, f32x4 (&acc)[8][MJ], const int m0, const int n0, const int wn,
                                               const int wm, const int lane) {
     const int frow = lane & 15, kg = lane >> 4;
@@ -85,7 +90,7 @@ __device__ __forceinline__ void g256_epilogue(const GemmArgs& a, f32x4 (&acc)[8]
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
             int nn = nw0 + i * 16 + frow;
-            nn = nn < a.N ? nn : a.N - 1;
+            if (!FULL) nn = nn < a.N ? nn : a.N - 1;
             lbv[i] = kg < 2 ? *reinterpret_cast<const bf16x8*>(a.lora_b + (size_t)nn * 16 + kg * 8) : zero8;   // rank 16 zero-padded to K = 32
         }
     }
@@ -94,11 +99,15 @@ __device__ __forceinline__ void g256_epilogue(const GemmArgs& a, f32x4 (&acc)[8]
     // strip then starts with an exposed L2 round trip (four per tile, tools/probe_gemm256.py).  Different strips touch
     // different rows, so the reordering is safe when y == resid.  LoRA segments start at multiples of 32 columns: one
     // fragment per PAIR of column tiles.
-    bf16x8 xfv2[2][LORA ? NT / 2 : 1];
-    uint4 rrv2[2][RESID ? NT / 2 : 1];
+    // PD strips are in flight: one ahead hides a round trip behind a strip's ~0.6 us of work when a second wave shares the SIMD
+    // (MJ = 4: the 8-wave kernel); the 4-wave kernel has nothing else to run and keeps three ahead (tools/probe_gemm256.py:
+    // proj + LoRA + residual 20.8 -> ?? us per tile)
+    constexpr int PD = MJ == 8 ? 4 : 2;
+    bf16x8 xfv2[PD][LORA ? NT / 2 : 1];
+    uint4 rrv2[PD][RESID ? NT / 2 : 1];
     auto load_strip = [&](int j, bf16x8 (&xf)[LORA ? NT / 2 : 1], uint4 (&rr)[RESID ? NT / 2 : 1]) __attribute__((always_inline)) {
         const int m = mw0 + j * 16 + frow;
-        const bool m_ok = m < a.M;
+        const bool m_ok = FULL || m < a.M;
         if (LORA && a.lora_b != nullptr) {
             const int mm = m_ok ? m : a.M - 1;
 #pragma unroll
@@ -114,7 +123,7 @@ __device__ __forceinline__ void g256_epilogue(const GemmArgs& a, f32x4 (&acc)[8]
 #pragma unroll
             for (int ip = 0; ip < NT / 2; ++ip) {
                 const int nb = nw0 + ip * 32;
-                rr[ip] = (m_ok && nb + 32 <= a.N)
+                rr[ip] = (FULL || (m_ok && nb + 32 <= a.N))
                              ? *reinterpret_cast<const uint4*>(a.resid + (size_t)m * a.N + nb + (kg & 1) * 16 + (kg >> 1) * 8)
                              : make_uint4(0, 0, 0, 0);
             }
@@ -127,19 +136,48 @@ __device__ __forceinline__ void g256_epilogue(const GemmArgs& a, f32x4 (&acc)[8]
 #pragma unroll
         for (int j = 0; j < MJ; ++j) {
             int mm = mw0 + j * 16 + frow;
-            mm = mm < a.M ? mm : a.M - 1;
+            if (!FULL) mm = mm < a.M ? mm : a.M - 1;
             posv[j] = a.tok_pos[mm];
             slotv[j] = a.tok_slot[mm];
         }
     }
-    load_strip(0, xfv2[0], rrv2[0]);
+    // ... and the rope rows of a strip (cos / sin of the row's position: c1, c2, s1, s2 per 16-column tile of a half head) one
+    // strip ahead, once for both heads of the wave: loaded inside each head they were a dependent round trip per head and strip,
+    // 16 of them per tile with nothing to run behind
+    uint2 ropev[2][EPI == DH_EPI_QKV ? 16 : 1];
+    auto load_rope = [&](int j, uint2 (&r)[EPI == DH_EPI_QKV ? 16 : 1]) __attribute__((always_inline)) {
+        if constexpr (EPI == DH_EPI_QKV) {
+            const int pos = posv[j];
+            auto rows = [&](auto hs_c) __attribute__((always_inline)) {
+                constexpr int HS = decltype(hs_c)::value, HALF = HS / 2, H2T = HS / 32;
+                const bf16_t* cp = a.rope_cos + (size_t)pos * HS + 4 * kg;
+                const bf16_t* sp = a.rope_sin + (size_t)pos * HS + 4 * kg;
+#pragma unroll
+                for (int t = 0; t < H2T; ++t) {
+                    r[4 * t + 0] = *reinterpret_cast<const uint2*>(cp + 16 * t);
+                    r[4 * t + 1] = *reinterpret_cast<const uint2*>(cp + HALF + 16 * t);
+                    r[4 * t + 2] = *reinterpret_cast<const uint2*>(sp + 16 * t);
+                    r[4 * t + 3] = *reinterpret_cast<const uint2*>(sp + HALF + 16 * t);
+                }
+            };
+            if (a.hs == 64) rows(std::integral_constant<int, 64>{});
+            else rows(std::integral_constant<int, 128>{});
+        }
+    };
+    static_for<PD - 1>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        load_strip(j, xfv2[j], rrv2[j]);
+    });
+    load_rope(0, ropev[0]);
     static_for<MJ>([&](auto jc) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value;
         const int m = mw0 + j * 16 + frow;
-        const bool m_ok = m < a.M;
-        if (j + 1 < MJ) load_strip(j + 1, xfv2[(j + 1) & 1], rrv2[(j + 1) & 1]);
-        bf16x8 (&xfv)[LORA ? NT / 2 : 1] = xfv2[j & 1];
-        uint4 (&rrv)[RESID ? NT / 2 : 1] = rrv2[j & 1];
+        const bool m_ok = FULL || m < a.M;
+        if constexpr (j + PD - 1 < MJ) load_strip(j + PD - 1, xfv2[(j + PD - 1) % PD], rrv2[(j + PD - 1) % PD]);
+        bf16x8 (&xfv)[LORA ? NT / 2 : 1] = xfv2[j % PD];
+        uint4 (&rrv)[RESID ? NT / 2 : 1] = rrv2[j % PD];
+        if constexpr (EPI == DH_EPI_QKV && j + 1 < MJ) load_rope(j + 1, ropev[(j + 1) & 1]);
+        uint2 (&rp)[EPI == DH_EPI_QKV ? 16 : 1] = ropev[j & 1];
         if constexpr (EPI == DH_EPI_QKV) {
             // ---- fused-QKV epilogue: finish LoRA, then per head of the wave's 128 columns rotate (q, k) and scatter
             // q -> q_out [tok, head, hs], k -> K cache, v -> V^T cache (fragment order, common.h), exactly the arithmetic
@@ -181,18 +219,15 @@ __device__ __forceinline__ void g256_epilogue(const GemmArgs& a, f32x4 (&acc)[8]
                 auto head = [&](auto hs_c, int hh) __attribute__((always_inline)) {
                     constexpr int HS = decltype(hs_c)::value, HALF = HS / 2, H2T = HS / 32;   // tiles per half head
                     const int col0 = nw0 + hh * HS;
-                    if (col0 >= a.N) return;                                                // wave-uniform
+                    if (!FULL && col0 >= a.N) return;                                       // wave-uniform
                     const int hidx = col0 / HS, g = hidx / (qpk + 2), jh = hidx % (qpk + 2);
                     const int t0 = hh * 2 * H2T;
                     if (jh <= qpk) {
-                        const bf16_t* cp = a.rope_cos + (size_t)pos * HS;
-                        const bf16_t* sp = a.rope_sin + (size_t)pos * HS;
                         uint2 p1[H2T], p2[H2T];
 #pragma unroll
                         for (int t = 0; t < H2T; ++t) {
-                            const int c0 = 16 * t + 4 * kg;
-                            const uint2 c1 = *reinterpret_cast<const uint2*>(cp + c0), c2 = *reinterpret_cast<const uint2*>(cp + HALF + c0);
-                            const uint2 s1 = *reinterpret_cast<const uint2*>(sp + c0), s2 = *reinterpret_cast<const uint2*>(sp + HALF + c0);
+                            const uint2 c1 = rp[EPI == DH_EPI_QKV ? 4 * t + 0 : 0], c2 = rp[EPI == DH_EPI_QKV ? 4 * t + 1 : 0];
+                            const uint2 s1 = rp[EPI == DH_EPI_QKV ? 4 * t + 2 : 0], s2 = rp[EPI == DH_EPI_QKV ? 4 * t + 3 : 0];
                             const bf16_t *c1p = (const bf16_t*)&c1, *c2p = (const bf16_t*)&c2, *s1p = (const bf16_t*)&s1, *s2p = (const bf16_t*)&s2;
                             float o1[4], o2[4];
 #pragma unroll
@@ -240,7 +275,7 @@ __device__ __forceinline__ void g256_epilogue(const GemmArgs& a, f32x4 (&acc)[8]
         // packed bf16 x4 of output tile i for this lane (all lanes run it: the swap below is wave-wide)
         auto tile_value = [&](int i) __attribute__((always_inline)) -> uint2 {
             const int nt = nw0 + i * 16, n = nt + kg * 4;
-            const bool ok = m_ok && n < a.N;
+            const bool ok = FULL || (m_ok && n < a.N);
             float o[4];
             if (EPI == DH_EPI_SWIGLU) {
 #pragma unroll
@@ -280,7 +315,7 @@ __device__ __forceinline__ void g256_epilogue(const GemmArgs& a, f32x4 (&acc)[8]
         for (int ip = 0; ip < NT / 2; ++ip) {
             uint2 ta = tile_value(2 * ip), tb = tile_value(2 * ip + 1);
             const int nb = nw0 + ip * 32;                        // first column of the pair (wave-uniform)
-            if (nb + 32 <= a.N) {
+            if (FULL || nb + 32 <= a.N) {
                 const auto rx = __builtin_amdgcn_permlane16_swap(ta.x, tb.x, false, false);
                 const auto ry = __builtin_amdgcn_permlane16_swap(ta.y, tb.y, false, false);
                 uint4 out = make_uint4(rx[0], ry[0], rx[1], ry[1]);
@@ -331,7 +366,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
     f32x4 acc[8][4];
     auto epilogue = [&](const int m0, const int n0) __attribute__((always_inline)) {
         G256_STAMP(2);
-        g256_epilogue<EPI, RESID, 4>(a, acc, m0, n0, wn, wm, lane);
+        g256_epilogue<EPI, RESID, 4, false>(a, acc, m0, n0, wn, wm, lane);
         G256_STAMP(3);
     };
     auto zero_acc = [&]() __attribute__((always_inline)) {
@@ -639,7 +674,7 @@ constexpr int w4_dma_before(int g) {         // pieces issued behind slots <= g
 static_assert(w4_dma_slot(15) < 128 && DH_W4_B1 < DH_W4_DMA0 && 15 * DH_W4_RD1STEP < DH_W4_B1, "B1 behind the last F1 read, in front of the first piece");
 static_assert(DH_W4_RD0 > DH_W4_B2 && DH_W4_RD0 + 15 * DH_W4_RD0STEP < 128, "F0 reads behind B2");
 
-template <int EPI, bool RESID>
+template <int EPI, bool RESID, bool PERSIST>
 __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -647,16 +682,13 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
     const int frow = lane & 15, kg = lane >> 4;
     int m0, n0;
     g256_tile_origin<EPI>(a, blockIdx.x, m0, n0);
+    G256_STAMP(0);
 
     f32x4 acc[8][8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     constexpr int BUF = 2 * TILE_B, OPB = TILE_B;    // bytes per stage / per operand of a stage (256 rows x 128 B)
     // ---- DMA sources: wave w moves row groups R = 8 w .. 8 w + 7 (8 rows x 128 B each) of W and of x
     uint32_t voA[8], voB[8];
+    auto setup_src = [&](const int m0, const int n0) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int R = wave * 8 + j;
@@ -671,6 +703,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
         m = m < a.M ? m : a.M - 1;
         voB[j] = ((uint32_t)m * (uint32_t)a.K + chunk * 8) * 2;
     }
+    };
+    setup_src(m0, n0);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     auto dma = [&](int d, int st, int b) __attribute__((always_inline)) {      // piece d (0..15: A0 B0 A1 B1 ...) of stage st -> buffer b
         const int j = d >> 1, R = wave_u * 8 + j;
@@ -731,30 +765,62 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
     };
     constexpr std::true_type T{};
     constexpr std::false_type F{};
+    auto first_stages = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int d = 0; d < 16; ++d) dma(d, 0, 0);
+        for (int d = 0; d < 16; ++d) dma(d, 0, 0);
 #pragma unroll
-    for (int d = 0; d < 16; ++d) dma(d, 1, 1);
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+        for (int d = 0; d < 16; ++d) dma(d, 1, 1);
+    };
+    first_stages();
+    const int nwg = a.nb_n * a.nb_m;
+    // PERSIST: the grid is one block per CU and a block walks tiles bid, bid + grid, ...; the first two stages of the NEXT tile are
+    // requested before the epilogue of the current one, so the epilogue, its store drain, the block dispatch and the first stage's
+    // latency overlap (the tile's K loop is only K / 64 = 32 iterations at K = 2048)
+    for (int vb = blockIdx.x, first = 1;; first = 0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) rd(r, 0, 0, fa0, fb0);
-    int st = 0;
-    for (; st + 2 < nst; ++st) iteration(T, T, st);
-    iteration(F, T, st);
-    iteration(F, F, st + 1);
-    // The compiler has no hazard model for an MFMA inside an asm: it would start the epilogue's v_accvgpr_read of a tile right
-    // behind that tile's last MFMA.  Wait the matrix pipe out, then tie every accumulator to an (empty) volatile asm behind the
-    // wait: volatile asms keep their order, and the epilogue's reads now depend on the later one.
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // first tile: stage 1 stays in flight; later tiles: the previous epilogue's stores share the counter with the loads
+        if (!PERSIST || first) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        G256_STAMP(1);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (i < 7) asm volatile("" : "+a"(acc[i][j]));
-            else asm volatile("" : "+v"(acc[i][j]));
+        for (int r = 0; r < 16; ++r) rd(r, 0, 0, fa0, fb0);
+        int st = 0;
+        for (; st + 2 < nst; ++st) iteration(T, T, st);
+        iteration(F, T, st);
+        iteration(F, F, st + 1);
+        // The compiler has no hazard model for an MFMA inside an asm: it would start the epilogue's v_accvgpr_read of a tile right
+        // behind that tile's last MFMA.  Wait the matrix pipe out, then tie every accumulator to an (empty) volatile asm behind the
+        // wait: volatile asms keep their order, and the epilogue's reads now depend on the later one.
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (i < 7) asm volatile("" : "+a"(acc[i][j]));
+                else asm volatile("" : "+v"(acc[i][j]));
+            }
+        const int vb_next = vb + (int)gridDim.x;
+        const bool more = PERSIST && vb_next < nwg;
+        int m0n = 0, n0n = 0;
+        if (more) {
+            __builtin_amdgcn_s_barrier();            // every wave has read its last fragments: both buffers are free
+            g256_tile_origin<EPI>(a, vb_next, m0n, n0n);
+            setup_src(m0n, n0n);
+            first_stages();
         }
-    g256_epilogue<EPI, RESID, 8>(a, acc, m0, n0, wn, wm, lane);
+        G256_STAMP(2);
+        if (m0 + BT2 <= a.M && n0 + (EPI == DH_EPI_SWIGLU ? 128 : BT2) <= a.N) g256_epilogue<EPI, RESID, 8, true>(a, acc, m0, n0, wn, wm, lane);
+        else g256_epilogue<EPI, RESID, 8, false>(a, acc, m0, n0, wn, wm, lane);
+        G256_STAMP(3);
+        if (!more) break;
+        vb = vb_next;
+        m0 = m0n;
+        n0 = n0n;
+    }
 }
 
 // two 64-deep stages at least; operands addressed through 32-bit buffer offsets
@@ -762,13 +828,35 @@ inline bool w4_ok(const GemmArgs& a) {
     return a.K >= 128 && (size_t)a.N * a.K * 2 < (1ull << 32) && (size_t)a.M * a.K * 2 < (1ull << 32);
 }
 
-template <int EPI, bool RESID>
-int launch_w4(const GemmArgs& a, hipStream_t s) {
-    auto kfn = gemm_nt256w4_kernel<EPI, RESID>;
+inline int g256_cu_count() {
+    static std::atomic<int> n_cu{0};
+    int cu = n_cu.load(std::memory_order_relaxed);
+    if (cu == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu = 256;
+        n_cu.store(cu, std::memory_order_relaxed);
+    }
+    return cu;
+}
+
+template <int EPI, bool RESID, bool PERSIST>
+int launch_w4p(const GemmArgs& a, hipStream_t s) {
+    auto kfn = gemm_nt256w4_kernel<EPI, RESID, PERSIST>;
     DH_MAX_LDS_ONCE(kfn, 4 * TILE_B);
-    hipLaunchKernelGGL(kfn, dim3(a.nb_n * a.nb_m), dim3(256), 4 * TILE_B, s, a);
+    int blocks = a.nb_n * a.nb_m;
+    if (PERSIST) blocks = blocks < g256_cu_count() ? blocks : g256_cu_count();   // one block per CU walks the tiles
+    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), 4 * TILE_B, s, a);
     DH_LAUNCH_CHECK();
     return 0;
+}
+
+template <int EPI, bool RESID>
+int launch_w4(const GemmArgs& a, hipStream_t s) {
+    // The next tile's first stages are requested in front of the epilogue; loads return in order, so an epilogue that loads
+    // (residual, x.A^T fragments, rope rows) would wait for those 64 KiB behind its first operand: persistent blocks only where
+    // the epilogue reads nothing (bench: all-persistent 715 utt/s, none 724)
+    const bool persist = g_w4_persist == 2 || (g_w4_persist == 1 && !RESID && (EPI == DH_EPI_PLAIN || EPI == DH_EPI_SWIGLU));
+    return persist ? launch_w4p<EPI, RESID, true>(a, s) : launch_w4p<EPI, RESID, false>(a, s);
 }
 
 template <int EPI, bool RESID, int PIPE>

@@ -10,7 +10,7 @@ if len(sys.argv) > 2 and sys.argv[1] == "--summary":
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
             if "gemm_nt256" in k or "Cijk" in k:
-                acc[k[:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                acc[k[:75]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, d in acc.items():
         print(k)
         for c, v in sorted(d.items()):
@@ -32,5 +32,21 @@ for v in (2, 5):   # 8-wave ping-pong, 4-wave full-line
     lib.dh_set_tuning(1, v)
     for _ in range(3):
         ops.linear(x, w, out=y)
+if "--epilogues" in sys.argv:   # the four prefill launches of a layer with their real epilogues (4-wave kernel)
+    M, d, I = 32768, 2048, 5632
+    x, act = rn(M, d), rn(M, I)
+    Wq, Wp, W1, W2, Wm = rn(2560, d), rn(d, d), rn(I, d), rn(I, d), rn(d, I)
+    xa48, xa16, Bq, Bp = rn(M, 48), rn(M, 16), rn(2560, 16), rn(d, 16)
+    H, G, hs, S = 32, 4, 64, 512
+    cos, sin = rn(S, hs), rn(S, hs)
+    nseq = M // S
+    kc = torch.zeros(nseq, G, S, hs, device=D, dtype=torch.bfloat16); vt = torch.zeros(nseq, G, hs, S, device=D, dtype=torch.bfloat16)
+    tok_slot = torch.arange(nseq, device=D, dtype=torch.int32).repeat_interleave(S)
+    tok_pos = torch.arange(S, device=D, dtype=torch.int32).repeat(nseq)
+    for _ in range(3):
+        ops.linear(x, W1, epilogue=ops.EPI_SWIGLU, w2=W2)
+        ops.linear(act, Wm, resid=x)
+        ops.linear_qkv_rope_cache(x, Wq, cos, sin, tok_slot, tok_pos, kc, vt, H, G, xa=xa48, lora_b=Bq)
+        ops.linear(x, Wp, epilogue=ops.EPI_LORA, xa=xa16, lora_b=Bp, lora_scale=1.0, splits=(d, d), resid=x)
 torch.cuda.synchronize()
 print("done")

@@ -19,7 +19,9 @@ def stamps(n):
     buf = np.zeros(8192 * 4, dtype=np.uint64)
     assert raw.dh_debug_g256_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
     return buf.reshape(8192, 4)[:n].astype(np.int64)
-lib.dh_set_tuning(1, 1)      # per-tile launches: a block = a tile
+import os
+lib.dh_set_tuning(1, int(os.environ.get("G256_VARIANT", "5")))      # 1: 8-wave ping-pong, 5: 4-wave full-line
+lib.dh_set_tuning(22, 0)     # per-tile launches: a block = a tile
 H, G, hs, S = 32, 4, 64, 512
 Wq, Wp = rn(2560, d), rn(d, d)
 xa48, xa16, Bq, Bp = rn(M, 48), rn(M, 16), rn(2560, 16), rn(d, 16)

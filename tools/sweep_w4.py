@@ -10,6 +10,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     from dualhyp_amd import ops, _lib
     lib = _lib.load()
     lib.dh_set_tuning(1, int(os.environ.get("W4_VARIANT", "5")))
+    lib.dh_set_tuning(22, int(os.environ.get("W4_PERSIST", "1")))
     D = "cuda:0"
     g = torch.Generator(device=D).manual_seed(0)
     rn = lambda *s: (torch.randn(*s, device=D, generator=g) * 0.05).bfloat16()
@@ -34,6 +35,10 @@ for name in sys.argv[1:]:
     env = dict(os.environ)
     if name.startswith("old"):
         env["W4_VARIANT"] = "4"
+    elif name == "default":
+        pass
+    elif name == "nopersist":
+        env["W4_PERSIST"] = "0"
     else:
         env["DUALHYP_HIP_LIB"] = str(ROOT / "tools" / "bin" / f"lib_{name}.so")
     r = subprocess.run([sys.executable, __file__, "--child"], env=env, capture_output=True, text=True, timeout=300)
