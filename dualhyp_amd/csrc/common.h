@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <type_traits>
+#include <utility>
 
 #include "../../include/dualhyp_hip.h"
 
@@ -60,6 +62,22 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+
+// The saddr form of the same request, written out: uniform base in an SGPR pair + one 32-bit byte offset per lane, LDS destination
+// (uniform) through M0.  From the builtin the compiler hoists zero-extended lane offsets out of a loop as 64-bit VGPR pairs and
+// issues a v_lshl_add_u64 plus the 64-bit-address form per request; the compiler does not count an asm load (wait with
+// explicit s_waitcnt vmcnt) and never waits before a ds_read that may alias its destination.
+__device__ __forceinline__ void glds16_saddr(const void* base_uniform, uint32_t lane_off, void* lds_wave_base) {
+    const uint32_t lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_wave_base;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(base_uniform), "s"(lds) : "memory", "m0");
+}
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>) (#pragma unroll gives up on big bodies, and a
+// loop that stays a loop indexes register arrays dynamically, i.e. puts them in scratch)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 // the same with the non-temporal policy (aux = 2): bytes this CU alone reads once (streamed weights)
 __device__ __forceinline__ void glds16_nt(const void* gsrc, void* lds_wave_base) {

@@ -54,12 +54,6 @@ __device__ __forceinline__ void g256_tile_origin(const GemmArgs& a, const int bi
     n0 = (EPI == DH_EPI_SWIGLU) ? tn * 128 : tn * BT2;
 }
 
-// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>) (#pragma unroll gives up on the big bodies below,
-// and a loop that stays a loop indexes the accumulator array dynamically, i.e. puts it in scratch)
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
-template <int N, class F>
-__device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 // The epilogue of a wave that owns 128 (n) x 16 MJ (m) of the block tile: acc[i][j] is the 16 x 16 tile of column tile i, row
 // strip j.  MJ = 4: the 8-wave kernel (waves 2 x 4), MJ = 8: the 4-wave kernel (waves 2 x 2).
 // FULL: the block tile lies inside the matrix — every bound below is then known at compile time, the epilogue has no exec-mask
@@ -709,14 +703,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
     auto dma = [&](int d, int st, int b) __attribute__((always_inline)) {      // piece d (0..15: A0 B0 A1 B1 ...) of stage st -> buffer b
         const int j = d >> 1, R = wave_u * 8 + j;
         char* dst = smem + b * BUF + R * 1024;
-        // uniform base + 32-bit lane offset: the saddr form of global_load_lds (no 64-bit VALU address arithmetic)
-        // the saddr form (uniform base in an SGPR pair + one 32-bit lane offset), written out: from the builtin the compiler
-        // hoists the zero-extended lane offsets out of the loop as 64-bit VGPR pairs and issues v_lshl_add_u64 + the
-        // 64-bit-address form per piece
-        auto issue = [&](const char* base, uint32_t vo, char* lds_dst) __attribute__((always_inline)) {
-            const uint32_t lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)lds_dst;
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vo), "s"(base), "s"(lds) : "memory", "m0");
-        };
+        auto issue = [&](const char* base, uint32_t vo, char* lds_dst) __attribute__((always_inline)) { glds16_saddr(base, vo, lds_dst); };   // common.h
         if (d & 1) {
             issue(reinterpret_cast<const char*>(a.x) + (size_t)st * 128, voB[j], dst + OPB);
         } else {

@@ -301,6 +301,11 @@ int dh_chain_tiled(const bf16_t* x, const bf16_t* w, const bf16_t* w_ext, float*
 // The pair sums of the K-slices (kps k-steps each) of x·[w; w_ext]^T: fp32 [ceil(nslices / 2)][M][n_main + n_ext], one
 // block per (tile, slice pair).  Tile shape by grid size: 128 x 256 on 8 waves (3 stages of 48 KiB) when that still gives
 // every CU a block, else 128 x 128 on 4 waves (dh_set_tuning key 17: 0 auto, 2 / 4 = waves along n).
+// Round 3, measured and not kept: the same 128 x 256 pair-sum tile on FOUR waves in the style of gemm256.hip's 4-wave kernel (one wave
+// per SIMD with 128 x 64, 3-stage ring, both k-steps of a stage in registers, one barrier per stage, asm MFMAs with pinned
+// accumulators; bit-equal): 16.8 / 16.6 / 24.5 us for qkv' / proj' / mlp' at 640 rows against 16.0 / 15.8 / 24.3 here.  A block
+// walks only 8 stages; the launch is bound by its 27 MB of fp32 pair sums, the first stage's latency and the launch itself, not
+// by the K walk.
 int g_pairs_wn = 0;
 int g_pairs_wt = 0;   // write-through (sc1) stores of the pair sums: measured neutral (decode 4.74-4.77 ms per token either way), off
 int dh_pairs_tiled(const bf16_t* x, const bf16_t* w, const bf16_t* w_ext, float* y32, int M, int n_main, int n_ext, int K,

@@ -137,6 +137,43 @@ def test_linear_tile_size_invariant(dev):
     assert torch.equal(ops.linear(xt, w)[-300:], ops.linear(xt[-300:].contiguous(), w))
 
 
+def test_linear_256_tile_variants_bit_equal(dev):
+    """The 256-tile prefill GEMM's loop variants (dh_set_tuning key 1: 2 = 8 waves in phase, 1 = 8 waves ping-pong, 5 = the
+    default four waves with 128 x 128 each, full-line stages and asm MFMAs; key 22: its persistent-block modes) run the same chain per
+    output — one accumulator, k ascending in steps of 32 — and share one epilogue: every epilogue must come out bit-identical, on
+    full tiles, on the ragged last row band (M = 8192 - 77: the run-time-bounded epilogue) and with more tiles than CUs (the
+    persistent walk, next tile's first stages requested in front of the epilogue)."""
+    from dualhyp_amd import ops, _lib
+    lib = _lib.load()
+    d, I, M = 2048, 1408, 8192 - 77
+    x = U((M, d), 1.0, "vx").to(dev)
+    w = U((2560, d), 0.05, "vw").to(dev)
+    r = U((M, 2560), 1.0, "vr").to(dev)
+    A48, B16 = U((48, d), 1 / math.sqrt(d), "va").to(dev), U((2560, 16), 0.05, "vb").to(dev)
+    w1, w2 = U((I, d), 0.05, "v1").to(dev), U((I, d), 0.05, "v2").to(dev)
+    act, wp, rr = U((M, I), 1.0, "vact").to(dev), U((d, I), 0.05, "vp").to(dev), U((M, d), 1.0, "vrr").to(dev)
+    xa = ops.linear(x, A48)
+
+    def run():
+        return [ops.linear(x, w), ops.linear(x, w, resid=r),
+                ops.linear(x, w, epilogue=ops.EPI_LORA, xa=xa, lora_b=B16, lora_scale=2.0, splits=(2048, 2304)),
+                ops.linear(x, w, epilogue=ops.EPI_LORA, xa=xa, lora_b=B16, lora_scale=1.0, splits=(2048, 2304), resid=r),
+                ops.linear(x, w1, epilogue=ops.EPI_SWIGLU, w2=w2), ops.linear(act, wp, resid=rr)]
+    names = ["plain", "plain + resid", "lora", "lora + resid", "swiglu", "K = 1408 + resid"]
+    try:
+        lib.dh_set_tuning(1, 2)
+        want = run()
+        assert float(want[0].float().abs().sum()) > 0
+        for variant, persist in ((1, 1), (5, 0), (5, 1), (5, 2)):
+            lib.dh_set_tuning(1, variant)
+            lib.dh_set_tuning(22, persist)
+            for nm, a, b in zip(names, want, run()):
+                assert torch.equal(a, b), f"variant {variant} persist {persist}: {nm} differs from the in-phase 8-wave kernel"
+    finally:
+        lib.dh_set_tuning(1, 5)
+        lib.dh_set_tuning(22, 1)
+
+
 @pytest.mark.parametrize("hs,n_head,n_groups,lora", [(64, 32, 4, True), (128, 32, 8, True), (64, 32, 4, False)])
 def test_qkv_gemm_with_rope_and_cache_epilogue(dev, hs, n_head, n_groups, lora):
     """dh_linear_qkv_rope_cache_bf16 (rope + KV append inside the 256-tile QKV GEMM's epilogue) against the two-step
@@ -160,18 +197,28 @@ def test_qkv_gemm_with_rope_and_cache_epilogue(dev, hs, n_head, n_groups, lora):
     mk = lambda: (torch.zeros((B, n_groups, s_max, hs), dtype=torch.bfloat16, device=dev),
                   torch.zeros((B, n_groups, hs, s_max), dtype=torch.bfloat16, device=dev))
     kc1, vt1 = mk()
-    kc2, vt2 = mk()
     xa = ops.linear(x, A48) if lora else None
     if lora:
         qkv = ops.linear(x, w, epilogue=ops.EPI_LORA, xa=xa, lora_b=B16, lora_scale=2.0, splits=(d, d + kv))
     else:
         qkv = ops.linear(x, w)
     q1 = ops.qkv_rope_cache(qkv, cos, sin, slot, pos, kc1, vt1, n_head, n_groups)
-    q2 = ops.linear_qkv_rope_cache(x, w, cos, sin, slot, pos, kc2, vt2, n_head, n_groups, xa=xa, lora_b=B16 if lora else None, lora_scale=2.0)
-    assert torch.equal(q1, q2), "rotated q differs"
-    assert torch.equal(kc1, kc2), "K cache differs"
-    assert torch.equal(vt1, vt2), "V^T cache differs"
-    assert float(kc2.float().abs().sum()) > 0 and float(vt2.float().abs().sum()) > 0
+    assert float(kc1.float().abs().sum()) > 0 and float(vt1.float().abs().sum()) > 0
+    # the default (four waves, block per tile), the same with persistent blocks (640 tiles on 256 CUs), and the 8-wave kernel
+    from dualhyp_amd import _lib
+    lib = _lib.load()
+    try:
+        for variant, persist in ((5, 1), (5, 2), (1, 1)):
+            lib.dh_set_tuning(1, variant)
+            lib.dh_set_tuning(22, persist)
+            kc2, vt2 = mk()
+            q2 = ops.linear_qkv_rope_cache(x, w, cos, sin, slot, pos, kc2, vt2, n_head, n_groups, xa=xa, lora_b=B16 if lora else None, lora_scale=2.0)
+            assert torch.equal(q1, q2), f"variant {variant} persist {persist}: rotated q differs"
+            assert torch.equal(kc1, kc2), f"variant {variant} persist {persist}: K cache differs"
+            assert torch.equal(vt1, vt2), f"variant {variant} persist {persist}: V^T cache differs"
+    finally:
+        lib.dh_set_tuning(1, 5)
+        lib.dh_set_tuning(22, 1)
 
 
 @pytest.mark.parametrize("M,d,I", [(50, 256, 384), (200, 2048, 5632), (300, 256, 384), (515, 2048, 5632)])
