@@ -41,11 +41,11 @@ WORKLOADS = {
                            what="DualHyp inference, TinyLlama-1.1B bf16 + LoRA r16 (q,k,v,proj), batch 32/GPU synthetic 5+5-hyp prompts, "
                                 "512-token prompt -> 64 generated tokens, greedy",
                            metric="corrected utterances/sec (TinyLlama-1.1B, 5+5 hyps, 512->64 tok)", dtype="bf16",
-                           kernel="gemm_nt256_kernel (prefill GEMMs: qkv+LoRA, proj+LoRA, fc_1/fc_2 SwiGLU, mlp proj)"),
+                           kernel="gemm_nt256w4_kernel (prefill GEMMs: qkv+LoRA, proj+LoRA, fc_1/fc_2 SwiGLU, mlp proj)"),
     "llama3-8b-bf16": dict(model="Llama-3-8B", prompt=1536, fp8=False, peak=2500.0, in_flight=4, prefill_batches=1,
                            what="DualHyp inference, Llama-3-8B bf16 + LoRA r16, batch 32/GPU synthetic 10+10-hyp prompts, 1536-token prompt -> 64 tokens, greedy",
                            metric="corrected utterances/sec (Llama-3-8B, 10+10 hyps, 1536->64 tok)", dtype="bf16",
-                           kernel="gemm_nt256_kernel (prefill GEMMs)"),
+                           kernel="gemm_nt256w4_kernel (prefill GEMMs)"),
     "finetune-tinyllama": dict(model="tiny-llama-1.1b-chat", prompt=560, fp8=False, peak=2500.0, in_flight=1, prefill_batches=1, train=True,
                                what="DualHyp LoRA fine-tune (finetune/ger.py --dual_hypotheses), TinyLlama-1.1B bf16 base + fp32 LoRA masters r16, "
                                     "micro-batch 1 x 560 tokens (512 masked prompt + 47 response + EOS), optimizer step = 32 utterances "
@@ -300,7 +300,7 @@ def main() -> None:
         flops = gemm_flops_per_prefill(cfg, sum(p.numel() for p in timed_prompts), B * a.steps, merged_lora=wl["fp8"])
         achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         traffic = None   # HBM-side bytes per launch from the committed PMC passes
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_gemm_v2.json")
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_gemm_w4.json")
         if os.path.exists(pmc) and a.config == "tinyllama-bf16":
             with open(pmc) as fh:
                 traffic = json.load(fh).get("traffic_bytes_per_launch_mean")
@@ -319,7 +319,7 @@ def main() -> None:
             "roofline": {"bound": "mfma", "kernel": wl["kernel"],
                          "achieved": achieved, "peak": wl["peak"], "unit": "TFLOP/s",
                          "frac": achieved / wl["peak"], "traffic": traffic,
-                         "traffic_source": ("profiles/r02_pmc_gemm_v2.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_gemm.py, mean bytes per "
+                         "traffic_source": ("profiles/r03_pmc_gemm_w4.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_gemm.py, mean bytes per "
                                             "launch; L2-miss traffic on the fabric, Infinity-Cache hits included)") if traffic is not None else
                                            "not collected for this workload (PMC passes exist for the headline config's GEMMs only)",
                          "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),

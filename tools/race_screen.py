@@ -2,7 +2,8 @@
 """Race screen for the kernels whose LDS hand-over rests on counted s_waitcnt + raw s_barrier (cdna_hip_programming.md
 §5 'place reads by the vmcnt/barrier count, never by clean runs'): many launches on fresh random data, several
 shapes, compared bit for bit with a structurally different kernel that computes the same chains.
-  * 256-tile GEMM: ping-pong loop (variant 1), 4-stage loop (2) and persistent ping-pong blocks (4) vs the __syncthreads double buffer (3)
+  * 256-tile GEMM: ping-pong loop (variant 1), 4-stage loop (2), persistent ping-pong blocks (4) and the four-wave full-line kernel (5,
+    per tile and with persistent blocks) vs the __syncthreads double buffer (3)
   * 128-tile GEMM: 4-stage counted-wait loop vs the 2-stage __syncthreads loop
   * decode GEMMs: gemm_mid (loader waves) vs gemm_dt (tiled) rows; tiled chain vs ordered sum of K-sliced partials"""
 import sys, torch
@@ -23,22 +24,27 @@ for (M, N, K) in [(16384, 2560, 2048), (4096, 2048, 5632), (1024, 768, 512), (77
     for it in range(REPS):
         x, w, r = rn(M, K), rn(N, K) * 0.1, rn(M, N)
         outs = []
-        for v in (3, 1, 2, 4):
+        for v in (3, 1, 2, 4, 5, 5):
             lib.dh_set_tuning(1, v)
+            lib.dh_set_tuning(22, 2 if len(outs) == 5 else 0)     # the second pass of variant 5: persistent blocks for every epilogue
             outs.append(ops.linear(x, w, resid=r))
+        lib.dh_set_tuning(22, 1)
         check(f"gemm256 pingpong M={M} N={N} K={K} it={it}", outs[1], outs[0])
         check(f"gemm256 pipe M={M} N={N} K={K} it={it}", outs[2], outs[0])
         check(f"gemm256 persistent M={M} N={N} K={K} it={it}", outs[3], outs[0])
+        check(f"gemm256 four waves M={M} N={N} K={K} it={it}", outs[4], outs[0])
+        check(f"gemm256 four waves persistent M={M} N={N} K={K} it={it}", outs[5], outs[0])
         if N % 64 == 0 and it % 4 == 0:
             w2 = rn(N, K) * 0.1
             so = []
-            for v in (3, 1, 4):
+            for v in (3, 1, 4, 5):
                 lib.dh_set_tuning(1, v)
                 so.append(ops.linear(x, w, epilogue=ops.EPI_SWIGLU, w2=w2))
             check(f"gemm256 swiglu M={M} N={N} K={K} it={it}", so[1], so[0])
             check(f"gemm256 swiglu persistent M={M} N={N} K={K} it={it}", so[2], so[0])
+            check(f"gemm256 swiglu four waves (persistent) M={M} N={N} K={K} it={it}", so[3], so[0])
     print(f"gemm256 {M}x{N}x{K}: {REPS} runs done", flush=True)
-lib.dh_set_tuning(1, 4)
+lib.dh_set_tuning(1, 5)
 for (M, N, K) in [(560, 2048, 2048), (560, 2560, 2048), (200, 512, 5632), (100, 128, 64)]:
     for it in range(REPS):
         x, w = rn(M, K), rn(N, K) * 0.1
@@ -47,7 +53,7 @@ for (M, N, K) in [(560, 2048, 2048), (560, 2560, 2048), (200, 512, 5632), (100, 
         lib.dh_set_tuning(9, 4); b = ops.linear(x, w)
         check(f"gemm128 4-stage M={M} N={N} K={K} it={it}", b, a)
     print(f"gemm128 {M}x{N}x{K}: {REPS} runs done", flush=True)
-lib.dh_set_tuning(1, 4); lib.dh_set_tuning(9, 0)
+lib.dh_set_tuning(1, 5); lib.dh_set_tuning(9, 0)
 lib.dh_set_tuning(4, 2)
 for (M, d, I) in [(256, 2048, 5632), (1024, 2048, 5632), (100, 512, 768)]:
     for it in range(REPS):
