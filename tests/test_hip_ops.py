@@ -159,7 +159,15 @@ def test_linear_256_tile_variants_bit_equal(dev):
                 ops.linear(x, w, epilogue=ops.EPI_LORA, xa=xa, lora_b=B16, lora_scale=2.0, splits=(2048, 2304)),
                 ops.linear(x, w, epilogue=ops.EPI_LORA, xa=xa, lora_b=B16, lora_scale=1.0, splits=(2048, 2304), resid=r),
                 ops.linear(x, w1, epilogue=ops.EPI_SWIGLU, w2=w2), ops.linear(act, wp, resid=rr)]
-    names = ["plain", "plain + resid", "lora", "lora + resid", "swiglu", "K = 1408 + resid"]
+    # ragged N: the last column tile is partly outside the matrix (N = 2464 = 9.6 tiles; 1344 SwiGLU pairs = 10.5 tiles of 128)
+    wr, rrr = w[:2464].contiguous(), r[:, :2464].contiguous()
+    w1r, w2r = w1[:1344].contiguous(), w2[:1344].contiguous()
+
+    def run_ragged():
+        return [ops.linear(x, wr), ops.linear(x, wr, resid=rrr), ops.linear(x, w1r, epilogue=ops.EPI_SWIGLU, w2=w2r)]
+    _run = run
+    run = lambda: _run() + run_ragged()
+    names = ["plain", "plain + resid", "lora", "lora + resid", "swiglu", "K = 1408 + resid", "plain N = 2464", "plain + resid N = 2464", "swiglu I = 1344"]
     try:
         lib.dh_set_tuning(1, 2)
         want = run()
