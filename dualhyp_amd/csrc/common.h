@@ -27,8 +27,14 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
 // reference's eager bf16 tensor program
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
 
+// two values -> one dword of two bf16 (lo in bits 0..15): ONE v_cvt_pk_bf16_f32.  Written as two scalar conversions + shift + or
+// the compiler only sometimes finds the packed form (the prefill attention loop had 32 single conversions, 16 shifts and 16
+// ors per 32 probabilities); same rounding either way (RNE, the instruction's NaN handling).
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 // ---- wave64 reductions ------------------------------------------------------------------

@@ -31,14 +31,17 @@ typedef uint16_t dh_bf16;
 int dh_abi_version(void);
 /* Kernel-variant selector for A/B measurements inside one process (bench.py --tune k=v); never needed in production,
  * keys 4, 10 and 16 select a different fp32 summation order (low bits change), no other key changes a result bit.  Keys: 0 decode partial-sum GEMM (0 = K split over the waves of a block,
- * 1 = row-parallel with x staged in LDS); 1 prefill GEMM (0 = always 128x128 tiles, 1..3 = 256x256 loop variants, 4 = persistent blocks, the default);
+ * 1 = row-parallel with x staged in LDS); 1 prefill GEMM (0 = always 128x128 tiles, 1..3 = 256x256 loop variants on eight waves, 4 = those with persistent blocks,
+ * 5 = the default: 256x256 on four waves with full-line 64-deep stages, round 3);
  * 2 SwiGLU streaming variant; 3 gemm_mid on/off; 4 phase pin of dh_linear_bf16 (0 by shape, 1 tiled, 2 decode);
  * 5 band height of the 256-tile walk; 6 / 7 first row count of the tiled decode kernels (fused epilogues / chain sums);
  * 8 gemm_dt stages; 9 128-tile stages; 10 decode steps from this many rows on the prefill kernels (0 = never);
  * 11 column tiles per wave of the K-sliced kernel; 12 rope + cache append fused into the QKV GEMM (1) or two launches;
  * 13 W through the per-wave LDS ring in gemm_mid (1) or straight to VGPRs; 14 row groups per block of the K-sliced
  * kernel above 128 rows (0 = by grid size, 8, 10); 15 8-wave SwiGLU tile in gemm_dt (0 = from 256 rows, 1 always,
- * -1 never); 16 k-steps per K-slice for K <= 4096 (8 or 16). */
+ * -1 never); 16 k-steps per K-slice for K <= 4096 (8 or 16); 17 / 18 / 21 pair-sum decode GEMM (tile width, first row count, sc1 stores);
+ * 19 / 20 fp8 tile edge and band height; 22 persistent blocks of the 4-wave prefill GEMM (0 never, 1 where the epilogue loads nothing: default,
+ * 2 always). */
 int dh_set_tuning(int key, int value);
 const char* dh_last_error(void);
 /* Name of the first visible device's gcnArch ("gfx950") into buf; fails when no GPU. */
