@@ -39,6 +39,8 @@ __global__ __launch_bounds__(HS == 64 ? 1024 : 512) void attn_prefill_kernel(
     constexpr int TILE_B = HS * 32 * 2;   // bytes of one 32-key tile of K (and of V^T)
     // two stages of (two 32-key tiles of K, two of V^T): the tiles of step kt+1 are DMA'd (global_load_lds; the
     // cache is already in fragment order, so the copy is linear) while step kt is multiplied
+    // (Round 3, measured and not kept: FOUR stages at head size 64, DMA three steps ahead with counted waits — 217 us per launch against
+    //  209: the 40 % of wave cycles parked at waits (tools/pmc_attn_prefill.py: SQ_WAIT_ANY 100.6 M of 251 M) are not DMA latency.)
     __shared__ __attribute__((aligned(16))) char sKV[2][4 * TILE_B];
 
     const int seq = blockIdx.z, g = blockIdx.y;
