@@ -147,9 +147,45 @@ __global__ __launch_bounds__(WN * 128) void gemm_dt_kernel(DtArgs a) {
     int in_seg = 0;
     for (int kt = 0; kt < nk; ++kt) {
         // ring slot (kt+NSTAGE-1) % NSTAGE was last read in iteration kt-1, which ended with a barrier
-        if (kt + NSTAGE - 1 < nk) stage(kt + NSTAGE - 1);
+        const bool pre = kt + NSTAGE - 1 < nk;
         const char* sA = smem + (kt % NSTAGE) * STAGE;
         const char* sB = sA + ASZ;
+        if constexpr (WN == 4) {
+        // 8-wave tile (round 3): both k-steps' fragments are requested first and the stage's DMA pieces go out in two halves, in front of
+        // each k-step's MFMAs — a piece's issue takes the wave tens of cycles, six in a row at the top of the iteration idle the matrix
+        // pipe (SwiGLU 108 -> 104 us at 2048 rows, lm_head 121 -> 113 at 640, pair sums 24.2 -> 23.2 for mlp'; the 4-wave tile, two blocks
+        // per CU on 128 registers, spills with the second fragment set: 43 -> 74 us)
+        bf16x8 fa[2][4], fb[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int co = ((ks * 4 + kg) ^ sw) << 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fa[ks][i] = *reinterpret_cast<const bf16x8*>(sA + offA + i * 2048 + co);
+                fb[ks][i] = *reinterpret_cast<const bf16x8*>(sB + offB + i * 2048 + co);
+            }
+        }
+        char* dA = smem + ((kt + NSTAGE - 1) % NSTAGE) * STAGE;
+        char* dB = dA + ASZ;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (pre) {
+                if (ks == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) glds16(srcA[j] + (kt + NSTAGE - 1) * BKD, dA + (wave * 4 + j) * 1024);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) glds16(srcB[j] + (kt + NSTAGE - 1) * BKD, dB + (wave * NB + j) * 1024);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    cur[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], fb[ks][j], cur[i][j], 0, 0, 0);
+        }
+        } else {
+        if (pre) stage(kt + NSTAGE - 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int co = ((ks * 4 + kg) ^ sw) << 4;
@@ -164,6 +200,7 @@ __global__ __launch_bounds__(WN * 128) void gemm_dt_kernel(DtArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     cur[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], cur[i][j], 0, 0, 0);
+        }
         }
         if (++in_seg == seg_kt || kt + 1 == nk) {     // end of a chain segment: fold it in, in order
             in_seg = 0;
