@@ -40,7 +40,11 @@ __global__ __launch_bounds__(HS == 64 ? 1024 : 512) void attn_prefill_kernel(
     // two stages of (two 32-key tiles of K, two of V^T): the tiles of step kt+1 are DMA'd (global_load_lds; the
     // cache is already in fragment order, so the copy is linear) while step kt is multiplied
     // (Round 3, measured and not kept: FOUR stages at head size 64, DMA three steps ahead with counted waits — 217 us per launch against
-    //  209: the 40 % of wave cycles parked at waits (tools/pmc_attn_prefill.py: SQ_WAIT_ANY 100.6 M of 251 M) are not DMA latency.)
+    //  209: the 40 % of wave cycles parked at waits (tools/pmc_attn_prefill.py: SQ_WAIT_ANY 100.6 M of 251 M) are not DMA latency.
+    //  Nor are they instruction count or phase lock-step, as far as two more experiments go: the subtraction and the log2 e
+    //  multiplication of the softmax on packed pairs (24 fewer VALU instructions per step) 207-210 us; S of step kt+1 issued in front
+    //  of the softmax of step kt (software pipelining inside the wave, bit-identical, one more S tile: 163 VGPRs = one block per
+    //  CU 284 us, forced to 128 with 17 spills 277 us).)
     __shared__ __attribute__((aligned(16))) char sKV[2][4 * TILE_B];
 
     const int seq = blockIdx.z, g = blockIdx.y;
