@@ -44,6 +44,8 @@ SIGNATURES = {
     "dh_qkv_rope_cache_bf16": (I, [P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P]),
     "dh_linear_bf16": (I, [P, P, P, I, I, I, I, P, P, I, P, F, I, I, P, P, P, P]),
     "dh_linear_qkv_rope_cache_bf16": (I, [P, P, I, I, P, I, P, F, P, P, P, P, P, P, P, I, I, I, I, P]),
+    "dh_linear_lora_bf16": (I, [P, P, P, I, I, I, P, P, F, I, I, P, P, P]),
+    "dh_linear_qkv_lora_rope_cache_bf16": (I, [P, P, I, I, P, P, F, P, P, P, P, P, P, P, I, I, I, I, P, P]),
     "dh_linear_partial_bf16": (I, [P, P, P, P, I, I, I, I, I, P]),
     "dh_linear_chain_bf16": (I, [P, P, P, P, I, I, I, I, I, P]),
     "dh_linear_partial_pairs_bf16": (I, [P, P, P, P, I, I, I, I, I, P]),
@@ -109,7 +111,7 @@ def load() -> C.CDLL:
             raise DualHypHipError(f"libdualhyp_hip.so does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.dh_abi_version() != 3:
+    if lib.dh_abi_version() != 4:
         raise DualHypHipError("libdualhyp_hip.so ABI version mismatch")
     _lib = lib
     return lib

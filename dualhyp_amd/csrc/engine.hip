@@ -155,15 +155,19 @@ int run_layers(dh_engine* e, const int64_t* ids, int n_tok, int n_seq, int max_q
         if ((rc = dh_rmsnorm_bf16(e->x, nullptr, W.norm_1, e->xn, nullptr, n_tok, d, D.norm_eps, rt, s))) return rc;
         // large packed prefills: rope + KV append ride in the QKV GEMM's epilogue (same bits, no pass over the qkv tensor)
         const bool fuse_qkv = !decode && g_fuse_qkv_rope && dh_linear_is_big(n_tok, e->qkv_dim, DH_EPI_LORA);
-        if (W.attn_lora_a)
+        // x.A^T: inside the QKV GEMM's K loop on the fused large-prefill path (dh_linear_qkv_lora_rope_cache_bf16 decides), else a launch
+        if (W.attn_lora_a && !fuse_qkv)
             if ((rc = linear(e, e->xn, W.attn_lora_a, e->xa, n_tok, 48, d, DH_EPI_PLAIN, nullptr, nullptr, 0, nullptr, 0, 0,
                              nullptr, nullptr, nullptr, s, false))) return rc;
         if (fuse_qkv) {
             TimeScope t(e, 0, s);
-            if ((rc = dh_linear_qkv_rope_cache_bf16(e->xn, W.attn_w, n_tok, d, W.attn_lora_a ? e->xa : nullptr, 48,
-                                                    W.attn_lora_a ? W.attn_lora_b : nullptr, D.lora_scale, D.rope_cos,
-                                                    D.rope_sin, e->tok_slot, e->tok_pos, e->qrot, kc, vtc, H, G, hs,
-                                                    e->s_max, s))) return rc;
+            if (W.attn_lora_a) {
+                if ((rc = dh_linear_qkv_lora_rope_cache_bf16(e->xn, W.attn_w, n_tok, d, W.attn_lora_a, W.attn_lora_b, D.lora_scale,
+                                                             D.rope_cos, D.rope_sin, e->tok_slot, e->tok_pos, e->qrot, kc, vtc, H, G,
+                                                             hs, e->s_max, e->xa, s))) return rc;
+            } else if ((rc = dh_linear_qkv_rope_cache_bf16(e->xn, W.attn_w, n_tok, d, nullptr, 48, nullptr, D.lora_scale, D.rope_cos,
+                                                           D.rope_sin, e->tok_slot, e->tok_pos, e->qrot, kc, vtc, H, G, hs,
+                                                           e->s_max, s))) return rc;
         } else {
         if (W.attn_lora_a) {
             if ((rc = linear(e, e->xn, W.attn_w, e->qkv, n_tok, e->qkv_dim, d, DH_EPI_LORA, nullptr, e->xa, 48,
@@ -185,10 +189,10 @@ int run_layers(dh_engine* e, const int64_t* ids, int n_tok, int n_seq, int max_q
                                            max_q_len, H, G, hs, e->s_max, s))) return rc;
         }
         if (W.proj_lora_a) {
-            if ((rc = linear(e, e->att, W.proj_lora_a, e->xa, n_tok, 16, d, DH_EPI_PLAIN, nullptr, nullptr, 0, nullptr, 0, 0,
-                             nullptr, nullptr, nullptr, s, false))) return rc;
-            if ((rc = linear(e, e->att, W.proj_w, e->x, n_tok, d, d, DH_EPI_LORA, nullptr, e->xa, 16, W.proj_lora_b, d, d,
-                             nullptr, nullptr, e->x, s, true))) return rc;
+            // down-projection in the GEMM's K loop where the launch runs on the 4-wave 256-tile kernel, else its own launch (same bits)
+            TimeScope t(e, e->phase_decode ? 1 : 0, s);
+            if ((rc = dh_linear_lora_impl(e->att, W.proj_w, e->x, n_tok, d, d, W.proj_lora_a, W.proj_lora_b, D.lora_scale, d, d, e->x,
+                                          e->xa, e->phase_decode && !e->decode_tiled ? 2 : 1, s))) return rc;
         } else {
             if ((rc = linear(e, e->att, W.proj_w, e->x, n_tok, d, d, DH_EPI_PLAIN, nullptr, nullptr, 0, nullptr, 0, 0,
                              nullptr, nullptr, e->x, s, true))) return rc;

@@ -8,6 +8,7 @@ struct GemmArgs {
     const bf16_t* w2;
     bf16_t* y;
     const bf16_t* xa;
+    const bf16_t* lora_a;   // non-null: x.A^T is computed inside the 4-wave 256-tile kernel's K loop ([16 per segment][K]); xa is then unused
     const bf16_t* lora_b;
     const bf16_t* vec_a;
     const bf16_t* vec_b;
@@ -35,6 +36,8 @@ constexpr int DH_EPI_QKV = 4;   // internal: LoRA (optional) + rope + cache appe
 
 // M <= 32: one pass over W straight from HBM to registers (gemm_skinny.hip)
 int dh_linear_skinny(const GemmArgs& a, int epilogue, hipStream_t s);
+// the in-GEMM LoRA down-projection can run for these arguments (4-wave 256-tile kernel, tile-aligned segments): gemm256.hip
+bool dh_linear_256_xa_ok(const GemmArgs& a, int epilogue);
 
 // decode phase, M <= 256 rows from several batches in one launch (gemm_mid.hip)
 bool dh_linear_mid_ok(const GemmArgs& a, int epilogue);
@@ -67,6 +70,10 @@ extern int g_gemm_variant;   // 0: always the 128-tile kernel; 1 / 2 / 3: 256-ti
 // 1 = tiled MFMA kernel whatever M, 2 = decode phase (streaming kernels up to 256 rows).  The engine pins the choice per PHASE (prefill = tiled,
 // single-token decode = skinny) so a sequence's result never depends on how many other
 // sequences were packed into the same call (fp32 summation order differs between the two).
+// the LORA epilogue with the down-projection x.A^T computed by the library: inside the 4-wave 256-tile kernel's K loop where possible,
+// else one more dh_linear_impl launch into xa_work (gemm.hip)
+int dh_linear_lora_impl(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N, int K, const dh_bf16* lora_a, const dh_bf16* lora_b,
+                        float lora_scale, int split0, int split1, const dh_bf16* resid, dh_bf16* xa_work, int kernel, hipStream_t s);
 int dh_linear_impl(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N, int K, int epilogue,
                    const dh_bf16* w2, const dh_bf16* xa, int xa_ld, const dh_bf16* lora_b, float lora_scale,
                    int split0, int split1, const dh_bf16* vec_a, const dh_bf16* vec_b, const dh_bf16* resid,

@@ -261,10 +261,10 @@ bool dh_linear_is_big(int M, int N, int epilogue) {
     return g_gemm_variant >= 1 && M >= 256 && N >= (epilogue == DH_EPI_SWIGLU ? 128 : 256) && tiles256 >= 128;
 }
 
-extern "C" int dh_linear_qkv_rope_cache_bf16(const dh_bf16* x, const dh_bf16* w, int M, int K, const dh_bf16* xa, int xa_ld,
-                                             const dh_bf16* lora_b, float lora_scale, const dh_bf16* cos, const dh_bf16* sin,
-                                             const int32_t* tok_slot, const int32_t* tok_pos, dh_bf16* q_out, dh_bf16* k_cache,
-                                             dh_bf16* vT_cache, int n_head, int n_groups, int hs, int s_max, void* stream) {
+static int qkv_rope_cache_impl(const dh_bf16* x, const dh_bf16* w, int M, int K, const dh_bf16* xa, int xa_ld, const dh_bf16* lora_a,
+                               const dh_bf16* lora_b, float lora_scale, const dh_bf16* cos, const dh_bf16* sin,
+                               const int32_t* tok_slot, const int32_t* tok_pos, dh_bf16* q_out, dh_bf16* k_cache,
+                               dh_bf16* vT_cache, int n_head, int n_groups, int hs, int s_max, void* stream) {
     DH_CHECK(x && w && cos && sin && tok_slot && tok_pos && q_out && k_cache && vT_cache, "dh_linear_qkv_rope_cache_bf16: null argument");
     DH_CHECK(hs == 64 || hs == 128, "dh_linear_qkv_rope_cache_bf16: head_size %d unsupported", hs);
     DH_CHECK(n_groups > 0 && n_head % n_groups == 0 && K % BK == 0, "dh_linear_qkv_rope_cache_bf16: bad shape");
@@ -276,7 +276,62 @@ extern "C" int dh_linear_qkv_rope_cache_bf16(const dh_bf16* x, const dh_bf16* w,
     a.lora_scale = lora_scale;
     a.rope_cos = cos; a.rope_sin = sin; a.tok_slot = tok_slot; a.tok_pos = tok_pos; a.q_out = q_out; a.k_cache = k_cache;
     a.vT_cache = vT_cache; a.n_head = n_head; a.n_groups = n_groups; a.hs = hs; a.s_max = s_max;
+    if (lora_a != nullptr && lora_b != nullptr) {
+        // the down-projection inside the GEMM's K loop where the kernel and the segment boundaries allow it, else one launch into xa
+        a.lora_a = lora_a;
+        if (!dh_linear_256_xa_ok(a, DH_EPI_QKV)) {
+            a.lora_a = nullptr;
+            const int rc = dh_linear_impl(x, lora_a, const_cast<dh_bf16*>(xa), M, 48, K, DH_EPI_PLAIN, nullptr, nullptr, 0, nullptr, 1.f, 0, 0,
+                                          nullptr, nullptr, nullptr, 1, (hipStream_t)stream);
+            if (rc) return rc;
+        }
+    }
     return dh_linear_256(a, DH_EPI_QKV, (hipStream_t)stream);
+}
+
+extern "C" int dh_linear_qkv_rope_cache_bf16(const dh_bf16* x, const dh_bf16* w, int M, int K, const dh_bf16* xa, int xa_ld,
+                                             const dh_bf16* lora_b, float lora_scale, const dh_bf16* cos, const dh_bf16* sin,
+                                             const int32_t* tok_slot, const int32_t* tok_pos, dh_bf16* q_out, dh_bf16* k_cache,
+                                             dh_bf16* vT_cache, int n_head, int n_groups, int hs, int s_max, void* stream) {
+    return qkv_rope_cache_impl(x, w, M, K, xa, xa_ld, nullptr, lora_b, lora_scale, cos, sin, tok_slot, tok_pos, q_out, k_cache, vT_cache,
+                               n_head, n_groups, hs, s_max, stream);
+}
+
+extern "C" int dh_linear_qkv_lora_rope_cache_bf16(const dh_bf16* x, const dh_bf16* w, int M, int K, const dh_bf16* lora_a,
+                                                  const dh_bf16* lora_b, float lora_scale, const dh_bf16* cos, const dh_bf16* sin,
+                                                  const int32_t* tok_slot, const int32_t* tok_pos, dh_bf16* q_out, dh_bf16* k_cache,
+                                                  dh_bf16* vT_cache, int n_head, int n_groups, int hs, int s_max, dh_bf16* xa_work,
+                                                  void* stream) {
+    DH_CHECK(lora_a && lora_b && xa_work, "dh_linear_qkv_lora_rope_cache_bf16: lora_a, lora_b and xa_work ([M, 48] bf16) are required");
+    return qkv_rope_cache_impl(x, w, M, K, xa_work, 48, lora_a, lora_b, lora_scale, cos, sin, tok_slot, tok_pos, q_out, k_cache, vT_cache,
+                               n_head, n_groups, hs, s_max, stream);
+}
+
+// dh_linear_bf16's LORA epilogue with the down-projection computed by the library (include/dualhyp_hip.h)
+int dh_linear_lora_impl(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N, int K, const dh_bf16* lora_a, const dh_bf16* lora_b,
+                        float lora_scale, int split0, int split1, const dh_bf16* resid, dh_bf16* xa_work, int kernel, hipStream_t s) {
+    DH_CHECK(x && w && y && lora_a && lora_b && xa_work, "dh_linear_lora_bf16: null argument");
+    DH_CHECK(M >= 0 && N > 0 && K > 0 && K % BK == 0 && N % 8 == 0, "dh_linear_lora_bf16: bad shape M=%d N=%d K=%d", M, N, K);
+    DH_CHECK(split0 % 32 == 0 && split1 % 32 == 0 && split0 <= split1, "dh_linear_lora_bf16: LoRA splits must be multiples of 32");
+    if (M == 0) return 0;
+    const int nseg = 1 + (split0 < N) + (split1 < N);
+    if (kernel != 2 && M > 32 && dh_linear_is_big(M, N, DH_EPI_LORA)) {
+        GemmArgs a{};
+        a.x = x; a.w = w; a.y = y; a.lora_a = lora_a; a.lora_b = lora_b; a.resid = resid; a.M = M; a.N = N; a.K = K;
+        a.xa_ld = 16 * nseg; a.split0 = split0; a.split1 = split1; a.lora_scale = lora_scale;
+        if (dh_linear_256_xa_ok(a, DH_EPI_LORA)) return dh_linear_256(a, DH_EPI_LORA, s);
+    }
+    const int rc = dh_linear_impl(x, lora_a, xa_work, M, 16 * nseg, K, DH_EPI_PLAIN, nullptr, nullptr, 0, nullptr, 1.f, 0, 0, nullptr, nullptr,
+                                  nullptr, kernel, s);
+    if (rc) return rc;
+    return dh_linear_impl(x, w, y, M, N, K, DH_EPI_LORA, nullptr, xa_work, 16 * nseg, lora_b, lora_scale, split0, split1, nullptr, nullptr,
+                          resid, kernel, s);
+}
+
+extern "C" int dh_linear_lora_bf16(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N, int K, const dh_bf16* lora_a,
+                                   const dh_bf16* lora_b, float lora_scale, int split0, int split1, const dh_bf16* resid,
+                                   dh_bf16* xa_work, void* stream) {
+    return dh_linear_lora_impl(x, w, y, M, N, K, lora_a, lora_b, lora_scale, split0, split1, resid, xa_work, g_linear_phase, (hipStream_t)stream);
 }
 
 int dh_linear_impl(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N, int K, int epilogue,

@@ -59,9 +59,11 @@ __device__ __forceinline__ void g256_tile_origin(const GemmArgs& a, const int bi
 // FULL: the block tile lies inside the matrix — every bound below is then known at compile time, the epilogue has no exec-mask
 // branches, and (what matters) the compiler can COUNT its loads: with predicated loads inside branches it waits vmcnt(0) before
 // the first store, i.e. for the operands of every strip requested ahead.
-template <int EPI, bool RESID, int MJ, bool FULL>
+// XS: the wave's x.A^T fragments come from an LDS image [256 rows of the block tile][16 bf16] (the 4-wave kernel's in-GEMM LoRA
+// down-projection) instead of from the global xa tensor; the block tile then lies in ONE LoRA segment.
+template <int EPI, bool RESID, int MJ, bool FULL, bool XS = false>
 __device__ __forceinline__ void g256_epilogue(const GemmArgs& a, f32x4 (&acc)[8][MJ], const int m0, const int n0, const int wn,
-                                              const int wm, const int lane) {
+                                              const int wm, const int lane, const char* xs = nullptr) {
     const int frow = lane & 15, kg = lane >> 4;
     const int mw0 = m0 + wm * (MJ * 16);
     // ---------------------------------------------------------------- epilogue
@@ -81,7 +83,7 @@ __device__ __forceinline__ void g256_epilogue(const GemmArgs& a, f32x4 (&acc)[8]
     constexpr bool LORA = EPI == DH_EPI_LORA || EPI == DH_EPI_QKV;   // QKV: skipped at run time when lora_b is null
     bf16x8 lbv[LORA ? NT : 1];
     // (EPI_LORA always has its B; the fused-QKV epilogue runs with or without LoRA: a uniform run-time branch)
-    const bool has_lora = EPI == DH_EPI_LORA || (LORA && a.lora_b != nullptr);
+    const bool has_lora = EPI == DH_EPI_LORA || XS || (LORA && a.lora_b != nullptr);
     if (has_lora) {
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
@@ -108,7 +110,12 @@ __device__ __forceinline__ void g256_epilogue(const GemmArgs& a, f32x4 (&acc)[8]
     auto load_strip = [&](int j, bf16x8 (&xf)[LORA ? NT / 2 : 1], uint4 (&rr)[RESID ? NT / 2 : 1]) __attribute__((always_inline)) {
         const int m = mw0 + j * 16 + frow;
         const bool m_ok = FULL || m < a.M;
-        if (has_lora) {
+        if constexpr (XS) {
+            // 16 bytes of the row's 16 values (kg 2, 3 re-read kg 0, 1 and are zeroed: rank 16 zero-padded to K = 32)
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(xs + (wm * (MJ * 16) + j * 16 + frow) * 32 + (kg & 1) * 16);
+#pragma unroll
+            for (int i = 0; i < NT / 2; ++i) xf[i] = kg < 2 ? v : zero8;
+        } else if (has_lora) {
             const int mm = m_ok ? m : a.M - 1;
 #pragma unroll
             for (int i = 0; i < NT / 2; ++i) {
@@ -662,20 +669,27 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
 #define DH_W4_RD0STEP 2
 #endif
 constexpr int w4_dma_slot(int d) { return DH_W4_DMA0 + d * DH_W4_DMANUM / DH_W4_DMADEN; }
-constexpr int w4_dma_at(int g) {             // the piece issued behind slot g, or -1
-    for (int d = 0; d < 16; ++d)
+constexpr int w4_dma_at(int g, int np = 16) {             // the piece issued behind slot g, or -1
+    for (int d = 0; d < np; ++d)
         if (w4_dma_slot(d) == g) return d;
     return -1;
 }
-constexpr int w4_dma_before(int g) {         // pieces issued behind slots <= g
+constexpr int w4_dma_before(int g, int np = 16) {         // pieces issued behind slots <= g
     int n = 0;
-    for (int d = 0; d < 16; ++d) n += w4_dma_slot(d) <= g;
+    for (int d = 0; d < np; ++d) n += w4_dma_slot(d) <= g;
     return n;
 }
+static_assert(w4_dma_slot(16) < 128 && 16 * DH_W4_RD1STEP < DH_W4_B1 && DH_W4_RD0 + 16 * DH_W4_RD0STEP < 128, "room for the 17th piece / read of the in-GEMM x.A^T");
 static_assert(w4_dma_slot(15) < 128 && DH_W4_B1 < DH_W4_DMA0 && 15 * DH_W4_RD1STEP < DH_W4_B1, "B1 behind the last F1 read, in front of the first piece");
 static_assert(DH_W4_RD0 > DH_W4_B2 && DH_W4_RD0 + 15 * DH_W4_RD0STEP < 128, "F0 reads behind B2");
 
-template <int EPI, bool RESID, bool PERSIST>
+// XA (LoRA epilogues): the LoRA down-projection bf16(x . A^T) of the block's 256 rows rides in the same K loop — the 16 rows of A
+// of the tile's segment are a 17th DMA piece per stage (2 KiB behind the x image), one more fragment read per k-step, and four more
+// MFMAs per wave and k-step on the x fragments already in registers (each wave of a wn pair takes four of the eight row tiles).
+// The same chain per output as the separate x.A^T launch (one accumulator, k ascending in steps of 32): same bits.  After the loop
+// the values are rounded to bf16 into an LDS image that the epilogue reads as MFMA fragments: no xa tensor, no x.A^T launch
+// (2 x 32 us per layer and prefill launch), no xa loads in the epilogue.
+template <int EPI, bool RESID, bool PERSIST, bool XA = false>
 __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -686,9 +700,13 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
     G256_STAMP(0);
 
     f32x4 acc[8][8];
-    constexpr int BUF = 2 * TILE_B, OPB = TILE_B;    // bytes per stage / per operand of a stage (256 rows x 128 B)
+    constexpr int OPB = TILE_B;                       // bytes per operand of a stage (256 rows x 128 B)
+    constexpr int BUF = 2 * TILE_B + (XA ? 2048 : 0); // bytes per stage (XA: + 16 rows of A)
+    constexpr int NP = XA ? 17 : 16;                  // DMA pieces per wave and stage
+    const char* xs_img = smem + 2 * BUF;              // XA: [256][16] bf16, written after the K loop
     // ---- DMA sources: wave w moves row groups R = 8 w .. 8 w + 7 (8 rows x 128 B each) of W and of x
-    uint32_t voA[8], voB[8];
+    uint32_t voA[8], voB[8], voX = 0;
+    const bf16_t* la_seg = nullptr;                   // XA: first of the 16 rows of A of this tile's segment
     auto setup_src = [&](const int m0, const int n0) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -704,6 +722,13 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
         m = m < a.M ? m : a.M - 1;
         voB[j] = ((uint32_t)m * (uint32_t)a.K + chunk * 8) * 2;
     }
+    if constexpr (XA) {
+        // rows 8 (w & 1) .. + 7 of the segment's 16 (waves 2, 3 repeat 0, 1: identical bytes to the same place, and every wave
+        // then has the same number of pieces in flight for the counted waits)
+        const int row = (wave & 1) * 8 + (lane >> 3);
+        voX = ((uint32_t)row * (uint32_t)a.K + ((lane & 7) ^ ((row >> 1) & 7)) * 8) * 2;
+        la_seg = a.lora_a + (size_t)((n0 >= a.split0) + (n0 >= a.split1)) * 16 * a.K;
+    }
     };
     setup_src(m0, n0);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -711,7 +736,9 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
         const int j = d >> 1, R = wave_u * 8 + j;
         char* dst = smem + b * BUF + R * 1024;
         auto issue = [&](const char* base, uint32_t vo, char* lds_dst) __attribute__((always_inline)) { glds16_saddr(base, vo, lds_dst); };   // common.h
-        if (d & 1) {
+        if (d == 16) {
+            issue(reinterpret_cast<const char*>(la_seg) + (size_t)st * 128, voX, smem + b * BUF + 2 * OPB + (wave_u & 1) * 1024);
+        } else if (d & 1) {
             issue(reinterpret_cast<const char*>(a.x) + (size_t)st * 128, voB[j], dst + OPB);
         } else {
             // rows 64..127 of a wave-row half: fc_2 (R & 8 == wave & 1)
@@ -722,9 +749,13 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
     const int sw = (frow >> 1) & 7;
     const int offA = (wn * 128 + frow) * 128, offB = OPB + (wm * 128 + frow) * 128;
     const int co[2] = {(kg ^ sw) << 4, ((4 + kg) ^ sw) << 4};
-    auto rd = [&](int r, int b, int ks, bf16x8 (&fa)[8], bf16x8 (&fb)[8]) __attribute__((always_inline)) {   // read r: 0..15 = b0 a0 b1 a1 ...
+    bf16x8 fax[2];                                    // XA: the A-of-LoRA fragment of each k-step of the current stage
+    f32x4 xacc[4];                                    // XA: x.A^T of row tiles 4 wn .. 4 wn + 3 of this wave's eight
+    bf16x8 xsel[4];                                   // XA: their x fragments of the current k-step
+    auto rd = [&](int r, int b, int ks, bf16x8 (&fa)[8], bf16x8 (&fb)[8]) __attribute__((always_inline)) {   // read r: 0..15 = b0 a0 b1 a1 ...; 16: A of LoRA
         const char* base = smem + b * BUF + co[ks];
-        if (r & 1) fa[r >> 1] = *reinterpret_cast<const bf16x8*>(base + offA + (r >> 1) * 2048);
+        if (r == 16) fax[ks] = *reinterpret_cast<const bf16x8*>(base + 2 * OPB + frow * 128);
+        else if (r & 1) fa[r >> 1] = *reinterpret_cast<const bf16x8*>(base + offA + (r >> 1) * 2048);
         else fb[r >> 1] = *reinterpret_cast<const bf16x8*>(base + offB + (r >> 1) * 2048);
     };
     auto mfma = [&](int t, const bf16x8 (&fa)[8], const bf16x8 (&fb)[8]) __attribute__((always_inline)) {
@@ -741,19 +772,40 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
             constexpr int g = decltype(gc)::value;
             if constexpr (g < 64) mfma(g, fa0, fb0);
             else mfma(g - 64, fa1, fb1);
-            if constexpr (g % DH_W4_RD1STEP == DH_W4_RD1STEP - 1 && g / DH_W4_RD1STEP < 16) rd(g / DH_W4_RD1STEP, b, 1, fa1, fb1);
+            // XA: the k-step's four x.A^T MFMAs behind its 64.  Their x fragments (row tiles 4 wn .. 4 wn + 3) are SELECTED into `xsel`
+            // by v_cndmask early in the phase: a branch on wn around the MFMAs makes the compiler merge the accumulators with
+            // v_mov copies right behind them, and it inserts no wait states behind an MFMA it cannot see inside an asm (the copies
+            // read half-finished sums: found as wrong values in all but the first tiles)
+            if constexpr (XA && (g == 4 || g == 68)) {
+#pragma unroll
+                for (int jx = 0; jx < 4; ++jx) {
+                    union { bf16x8 v; uint32_t u[4]; } lo, hi, r;
+                    lo.v = g < 64 ? fb0[jx] : fb1[jx];
+                    hi.v = g < 64 ? fb0[4 + jx] : fb1[4 + jx];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) r.u[e] = wn ? hi.u[e] : lo.u[e];
+                    xsel[jx] = r.v;
+                }
+            }
+            if constexpr (XA && (g == 63 || g == 127)) {
+                asm volatile("s_nop 1" ::: "memory");          // a VALU-written operand in front of an MFMA the compiler cannot see
+#pragma unroll
+                for (int jx = 0; jx < 4; ++jx)
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(xacc[jx]) : "v"(fax[g >> 6]), "v"(xsel[jx]));
+            }
+            if constexpr (g % DH_W4_RD1STEP == DH_W4_RD1STEP - 1 && g / DH_W4_RD1STEP < NP) rd(g / DH_W4_RD1STEP, b, 1, fa1, fb1);
             if constexpr (PRE && g == DH_W4_B1) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
-            if constexpr (PRE && w4_dma_at(g) >= 0) dma(w4_dma_at(g), st + 2, b);
+            if constexpr (PRE && w4_dma_at(g, NP) >= 0) dma(w4_dma_at(g, NP), st + 2, b);
             if constexpr (NXT && g == DH_W4_B2) {
                 // the pieces of stage s+2 issued so far stay in flight; everything older (stage s+1) has landed
-                if constexpr (PRE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(w4_dma_before(DH_W4_B2)) : "memory");
+                if constexpr (PRE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(w4_dma_before(DH_W4_B2, NP)) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
-            if constexpr (NXT && g >= DH_W4_RD0 && (g - DH_W4_RD0) % DH_W4_RD0STEP == 0 && (g - DH_W4_RD0) / DH_W4_RD0STEP < 16)
+            if constexpr (NXT && g >= DH_W4_RD0 && (g - DH_W4_RD0) % DH_W4_RD0STEP == 0 && (g - DH_W4_RD0) / DH_W4_RD0STEP < NP)
                 rd((g - DH_W4_RD0) / DH_W4_RD0STEP, b ^ 1, 0, fa0, fb0);
         });
     };
@@ -761,9 +813,9 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
     constexpr std::false_type F{};
     auto first_stages = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int d = 0; d < 16; ++d) dma(d, 0, 0);
+        for (int d = 0; d < NP; ++d) dma(d, 0, 0);
 #pragma unroll
-        for (int d = 0; d < 16; ++d) dma(d, 1, 1);
+        for (int d = 0; d < NP; ++d) dma(d, 1, 1);
     };
     first_stages();
     const int nwg = a.nb_n * a.nb_m;
@@ -775,13 +827,17 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (XA) {
+#pragma unroll
+            for (int jx = 0; jx < 4; ++jx) xacc[jx] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         // first tile: stage 1 stays in flight; later tiles: the previous epilogue's stores share the counter with the loads
-        if (!PERSIST || first) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        if (!PERSIST || first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         G256_STAMP(1);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) rd(r, 0, 0, fa0, fb0);
+        for (int r = 0; r < NP; ++r) rd(r, 0, 0, fa0, fb0);
         int st = 0;
         for (; st + 2 < nst; ++st) iteration(T, T, st);
         iteration(F, T, st);
@@ -797,6 +853,21 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
                 if (i < 7) asm volatile("" : "+a"(acc[i][j]));
                 else asm volatile("" : "+v"(acc[i][j]));
             }
+        if constexpr (XA) {
+#pragma unroll
+            for (int jx = 0; jx < 4; ++jx) asm volatile("" : "+v"(xacc[jx]));
+            // bf16(x . A^T) of this wave's four row tiles -> the LDS image [row of the block tile][16]: lane (frow, kg) holds values
+            // 4 kg .. 4 kg + 3 of row frow.  (The image lies behind the stage buffers: a persistent block's next stages may already
+            // be landing; the previous tile's epilogue finished reading it before this tile's K loop — barriers in between.)
+#pragma unroll
+            for (int jx = 0; jx < 4; ++jx) {
+                const int row = wm * 128 + (4 * wn + jx) * 16 + frow;
+                *reinterpret_cast<uint2*>(const_cast<char*>(xs_img) + row * 32 + kg * 8) =
+                    make_uint2(pack2bf(xacc[jx][0], xacc[jx][1]), pack2bf(xacc[jx][2], xacc[jx][3]));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
         const int vb_next = vb + (int)gridDim.x;
         const bool more = PERSIST && vb_next < nwg;
         int m0n = 0, n0n = 0;
@@ -807,8 +878,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
             first_stages();
         }
         G256_STAMP(2);
-        if (m0 + BT2 <= a.M && n0 + (EPI == DH_EPI_SWIGLU ? 128 : BT2) <= a.N) g256_epilogue<EPI, RESID, 8, true>(a, acc, m0, n0, wn, wm, lane);
-        else g256_epilogue<EPI, RESID, 8, false>(a, acc, m0, n0, wn, wm, lane);
+        if (m0 + BT2 <= a.M && n0 + (EPI == DH_EPI_SWIGLU ? 128 : BT2) <= a.N) g256_epilogue<EPI, RESID, 8, true, XA>(a, acc, m0, n0, wn, wm, lane, xs_img);
+        else g256_epilogue<EPI, RESID, 8, false, XA>(a, acc, m0, n0, wn, wm, lane, xs_img);
         G256_STAMP(3);
         if (!more) break;
         vb = vb_next;
@@ -833,15 +904,22 @@ inline int g256_cu_count() {
     return cu;
 }
 
-template <int EPI, bool RESID, bool PERSIST>
+template <int EPI, bool RESID, bool PERSIST, bool XA = false>
 int launch_w4p(const GemmArgs& a, hipStream_t s) {
-    auto kfn = gemm_nt256w4_kernel<EPI, RESID, PERSIST>;
-    DH_MAX_LDS_ONCE(kfn, 4 * TILE_B);
+    auto kfn = gemm_nt256w4_kernel<EPI, RESID, PERSIST, XA>;
+    constexpr int lds = 4 * TILE_B + (XA ? 2 * 2048 + 256 * 32 : 0);     // XA: + 16 rows of A per stage + the [256][16] image
+    DH_MAX_LDS_ONCE(kfn, lds);
     int blocks = a.nb_n * a.nb_m;
     if (PERSIST) blocks = blocks < g256_cu_count() ? blocks : g256_cu_count();   // one block per CU walks the tiles
-    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), 4 * TILE_B, s, a);
+    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(256), lds, s, a);
     DH_LAUNCH_CHECK();
     return 0;
+}
+
+// the in-GEMM x.A^T needs every 256-column tile inside one LoRA segment
+inline bool w4_xa_ok(const GemmArgs& a) {
+    auto aligned = [&](int sp) { return sp >= a.N || sp % BT2 == 0; };
+    return a.lora_a != nullptr && a.lora_b != nullptr && w4_ok(a) && aligned(a.split0) && aligned(a.split1) && g_gemm_variant == 5;
 }
 
 template <int EPI, bool RESID>
@@ -849,6 +927,9 @@ int launch_w4(const GemmArgs& a, hipStream_t s) {
     // The next tile's first stages are requested in front of the epilogue; loads return in order, so an epilogue that loads
     // (residual, x.A^T fragments, rope rows) would wait for those 64 KiB behind its first operand: persistent blocks only where
     // the epilogue reads nothing (bench: all-persistent 715 utt/s, none 724)
+    if constexpr (EPI == DH_EPI_LORA || EPI == DH_EPI_QKV) {
+        if (a.lora_a != nullptr) return launch_w4p<EPI, RESID, false, true>(a, s);      // w4_xa_ok checked by the caller
+    }
     const bool persist = g_w4_persist == 2 || (g_w4_persist == 1 && !RESID && (EPI == DH_EPI_PLAIN || EPI == DH_EPI_SWIGLU));
     return persist ? launch_w4p<EPI, RESID, true>(a, s) : launch_w4p<EPI, RESID, false>(a, s);
 }
@@ -890,6 +971,10 @@ int launch(const GemmArgs& a, hipStream_t s) {
 
 // argument checks are done by dh_linear_impl (gemm.hip)
 int g_gemm_gm = 0;   // 0: default 4 (4 x 8 tile rectangles per XCD: fewest operand streams, tools/tune_gemm.py + PMC), else forced
+
+bool dh_linear_256_xa_ok(const GemmArgs& a, int epilogue) {
+    return (epilogue == DH_EPI_LORA || epilogue == DH_EPI_QKV) && w4_xa_ok(a);
+}
 
 int dh_linear_256(GemmArgs a, int epilogue, hipStream_t s) {
     a.gm = g_gemm_gm > 0 ? g_gemm_gm : 4;

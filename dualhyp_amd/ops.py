@@ -134,6 +134,41 @@ def linear_qkv_rope_cache(x: torch.Tensor, w: torch.Tensor, cos: torch.Tensor, s
     return q
 
 
+def linear_lora(x: torch.Tensor, w: torch.Tensor, lora_a: torch.Tensor, lora_b: torch.Tensor, *, lora_scale: float = 1.0,
+                splits: Optional[Tuple[int, int]] = None, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = x W^T + scale * bf16(x A^T) B^T (+ resid) with the down-projection computed by the library (inside the GEMM's K loop on the
+    4-wave 256-tile kernel, else one more launch); lora_a [16 * nseg, K], lora_b [N, 16]; dh_linear_lora_bf16."""
+    x, w, lora_a, lora_b = _dev(x, name="x"), _dev(w, name="w"), _dev(lora_a, name="lora_a"), _dev(lora_b, name="lora_b")
+    K = x.size(-1)
+    M, N = x.numel() // K, w.size(0)
+    s0, s1 = splits if splits is not None else (N, N)
+    nseg = 1 + (s0 < N) + (s1 < N)
+    assert lora_a.shape == (16 * nseg, K) and lora_b.shape == (N, 16), (lora_a.shape, lora_b.shape)
+    if resid is not None:
+        _dev(resid, name="resid")
+    y = torch.empty((*x.shape[:-1], N), dtype=torch.bfloat16, device=x.device)
+    work = torch.empty((M, 16 * nseg), dtype=torch.bfloat16, device=x.device)
+    check(_lib.load().dh_linear_lora_bf16(_p(x), _p(w), _p(y), M, N, K, _p(lora_a), _p(lora_b), float(lora_scale), s0, s1, _p(resid),
+                                          _p(work), _stream()))
+    return y
+
+
+def linear_qkv_lora_rope_cache(x: torch.Tensor, w: torch.Tensor, lora_a: torch.Tensor, lora_b: torch.Tensor, cos: torch.Tensor,
+                               sin: torch.Tensor, tok_slot: torch.Tensor, tok_pos: torch.Tensor, k_cache: torch.Tensor,
+                               vT_cache: torch.Tensor, n_head: int, n_groups: int, *, lora_scale: float = 1.0) -> torch.Tensor:
+    """linear_qkv_rope_cache with the LoRA down-projection computed by the library (dh_linear_qkv_lora_rope_cache_bf16)."""
+    k = _Keep()
+    M, K = x.shape
+    hs = k_cache.size(-1)
+    q = torch.empty((M, n_head, hs), dtype=torch.bfloat16, device=x.device)
+    work = torch.empty((M, 48), dtype=torch.bfloat16, device=x.device)
+    i32 = torch.int32
+    check(_lib.load().dh_linear_qkv_lora_rope_cache_bf16(k(x), k(w), M, K, k(lora_a), k(lora_b), float(lora_scale), k(cos), k(sin),
+                                                         k(tok_slot, i32), k(tok_pos, i32), _p(q), _p(k_cache), _p(vT_cache), n_head,
+                                                         n_groups, hs, k_cache.size(2), _p(work), _stream()))
+    return q
+
+
 def attn_prefill(q: torch.Tensor, k_cache: torch.Tensor, vT_cache: torch.Tensor, seq_slot: torch.Tensor,
                  q_start: torch.Tensor, q_len: torch.Tensor, kv_pos0: torch.Tensor, max_q_len: int,
                  lse: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -26,7 +26,7 @@ extern "C" {
 
 typedef uint16_t dh_bf16;
 
-#define DH_ABI_VERSION 3
+#define DH_ABI_VERSION 4
 
 int dh_abi_version(void);
 /* Kernel-variant selector for A/B measurements inside one process (bench.py --tune k=v); never needed in production,
@@ -114,6 +114,23 @@ int dh_linear_qkv_rope_cache_bf16(const dh_bf16* x, const dh_bf16* w, int M, int
                                   const dh_bf16* lora_b, float lora_scale, const dh_bf16* cos, const dh_bf16* sin,
                                   const int32_t* tok_slot, const int32_t* tok_pos, dh_bf16* q_out, dh_bf16* k_cache,
                                   dh_bf16* vT_cache, int n_head, int n_groups, int hs, int s_max, void* stream);
+
+/* Round 3 (ABI 4): the same two entry points with the LoRA DOWN-projection computed by the library — ger/lora.py:159-166, 388-402:
+ *   after = W x ; after_A = lora_A(x) (bf16) ; after_B = lora_B(after_A) ; result = after + scaling * after_B
+ * lora_a: [16 * nseg, K] bf16, segment s in rows 16 s .. 16 s + 15 (rank zero-padded to 16; nseg = 1 + (split0 < N) + (split1 < N),
+ * 3 for the fused QKV projection).  Where the launch runs on the 4-wave 256-tile kernel and every segment boundary is a multiple of
+ * 256 columns, bf16(x . A^T) rides in the GEMM's own K loop (16 more rows per stage, 4 more MFMAs per wave and k-step on the x
+ * fragments already in registers, the result handed to the epilogue through LDS): no separate launch, no [M, 16 nseg] tensor, same
+ * bits.  Otherwise the library runs dh_linear_bf16(x, lora_a) into xa_work and then the LORA epilogue.  xa_work: [M, 16 nseg] bf16,
+ * always required (which path runs is the library's choice). */
+int dh_linear_lora_bf16(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N, int K, const dh_bf16* lora_a,
+                        const dh_bf16* lora_b, float lora_scale, int split0, int split1, const dh_bf16* resid,
+                        dh_bf16* xa_work, void* stream);
+int dh_linear_qkv_lora_rope_cache_bf16(const dh_bf16* x, const dh_bf16* w, int M, int K, const dh_bf16* lora_a,
+                                       const dh_bf16* lora_b, float lora_scale, const dh_bf16* cos, const dh_bf16* sin,
+                                       const int32_t* tok_slot, const int32_t* tok_pos, dh_bf16* q_out, dh_bf16* k_cache,
+                                       dh_bf16* vT_cache, int n_head, int n_groups, int hs, int s_max, dh_bf16* xa_work,
+                                       void* stream);
 
 /* fp32 partial sums for the fused decode consumers below (M <= 4096 rows, weight streaming):
  *   y32[p][m][n] = sum over K-slice p of x[m,:] . W'[n,:],  W' = [w (n_main rows) ; w_ext (n_ext rows)]

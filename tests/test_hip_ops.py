@@ -182,6 +182,51 @@ def test_linear_256_tile_variants_bit_equal(dev):
         lib.dh_set_tuning(22, 1)
 
 
+@pytest.mark.parametrize("M", [8192, 8192 - 77, 700])
+def test_linear_lora_down_projection_in_the_gemm(dev, M):
+    """dh_linear_lora_bf16 / dh_linear_qkv_lora_rope_cache_bf16 (ABI 4): the LoRA down-projection bf16(x A^T) computed by the library —
+    inside the 4-wave 256-tile kernel's K loop for large M with tile-aligned segments (M = 8192, and 8192 - 77 with a ragged last row
+    band), by a separate launch otherwise (M = 700: the 128-tile kernel; segment boundaries off the 256 grid) — must give the bits of
+    the caller-side two-step form xa = linear(x, A); linear(x, W, EPI_LORA, xa)."""
+    from dualhyp_amd import ops
+    from oracle import ger_oracle as O
+    d, kv = 2048, 256
+    N = d + 2 * kv
+    x = U((M, d), 1.0, "fx").to(dev)
+    w, wp = U((N, d), 0.05, "fw").to(dev), U((d, d), 0.05, "fwp").to(dev)
+    A48, B16 = U((48, d), 1 / math.sqrt(d), "fa").to(dev), U((N, 16), 0.05, "fb").to(dev)
+    A16, Bp = U((16, d), 1 / math.sqrt(d), "fap").to(dev), U((d, 16), 0.05, "fbp").to(dev)
+    res = U((M, d), 1.0, "fr").to(dev)
+    # QKV-shaped: three segments at 2048 / 2304 (multiples of 256)
+    want = ops.linear(x, w, epilogue=ops.EPI_LORA, xa=ops.linear(x, A48), lora_b=B16, lora_scale=2.0, splits=(d, d + kv))
+    assert torch.equal(ops.linear_lora(x, w, A48, B16, lora_scale=2.0, splits=(d, d + kv)), want)
+    # attn.proj-shaped: one segment, fused residual, lora_scale 1 (its own code path in the epilogue)
+    want = ops.linear(x, wp, epilogue=ops.EPI_LORA, xa=ops.linear(x, A16), lora_b=Bp, lora_scale=1.0, resid=res)
+    assert torch.equal(ops.linear_lora(x, wp, A16, Bp, lora_scale=1.0, resid=res), want)
+    # segment boundaries off the 256-column grid: the library falls back to the separate launch
+    want = ops.linear(x, w, epilogue=ops.EPI_LORA, xa=ops.linear(x, A48), lora_b=B16, lora_scale=2.0, splits=(d - 32, d + kv + 32))
+    assert torch.equal(ops.linear_lora(x, w, A48, B16, lora_scale=2.0, splits=(d - 32, d + kv + 32)), want)
+    if M < 8192 - 77:
+        return
+    # the fused QKV projection + rope + cache append
+    hs, n_head, n_groups, s_max = 64, 32, 4, 512
+    cos, sin = O.build_rope_cache(s_max, hs)
+    cos, sin = cos.to(dev), sin.to(dev)
+    i32 = torch.int32
+    nseq = (M + s_max - 1) // s_max
+    lens = [s_max] * (nseq - 1) + [M - s_max * (nseq - 1)]
+    slot = torch.cat([torch.full((n,), i, dtype=i32) for i, n in enumerate(lens)]).to(dev)
+    pos = torch.cat([torch.arange(n, dtype=i32) for n in lens]).to(dev)
+    mk = lambda: (torch.zeros((nseq, n_groups, s_max, hs), dtype=torch.bfloat16, device=dev),
+                  torch.zeros((nseq, n_groups, hs, s_max), dtype=torch.bfloat16, device=dev))
+    kc1, vt1 = mk()
+    kc2, vt2 = mk()
+    q1 = ops.linear_qkv_rope_cache(x, w, cos, sin, slot, pos, kc1, vt1, n_head, n_groups, xa=ops.linear(x, A48), lora_b=B16, lora_scale=2.0)
+    q2 = ops.linear_qkv_lora_rope_cache(x, w, A48, B16, cos, sin, slot, pos, kc2, vt2, n_head, n_groups, lora_scale=2.0)
+    assert torch.equal(q1, q2) and torch.equal(kc1, kc2) and torch.equal(vt1, vt2)
+    assert float(kc2.float().abs().sum()) > 0
+
+
 @pytest.mark.parametrize("hs,n_head,n_groups,lora", [(64, 32, 4, True), (128, 32, 8, True), (64, 32, 4, False)])
 def test_qkv_gemm_with_rope_and_cache_epilogue(dev, hs, n_head, n_groups, lora):
     """dh_linear_qkv_rope_cache_bf16 (rope + KV append inside the 256-tile QKV GEMM's epilogue) against the two-step
