@@ -3,7 +3,7 @@
 §5 'place reads by the vmcnt/barrier count, never by clean runs'): many launches on fresh random data, several
 shapes, compared bit for bit with a structurally different kernel that computes the same chains.
   * 256-tile GEMM: ping-pong loop (variant 1), 4-stage loop (2), persistent ping-pong blocks (4) and the four-wave full-line kernel (5,
-    per tile and with persistent blocks) vs the __syncthreads double buffer (3)
+    per tile and with persistent blocks; its in-GEMM LoRA down-projection vs two launches) vs the __syncthreads double buffer (3)
   * 128-tile GEMM: 4-stage counted-wait loop vs the 2-stage __syncthreads loop
   * decode GEMMs: gemm_mid (loader waves) vs gemm_dt (tiled) rows; tiled chain vs ordered sum of K-sliced partials"""
 import sys, torch
@@ -43,6 +43,11 @@ for (M, N, K) in [(16384, 2560, 2048), (4096, 2048, 5632), (1024, 768, 512), (77
             check(f"gemm256 swiglu M={M} N={N} K={K} it={it}", so[1], so[0])
             check(f"gemm256 swiglu persistent M={M} N={N} K={K} it={it}", so[2], so[0])
             check(f"gemm256 swiglu four waves (persistent) M={M} N={N} K={K} it={it}", so[3], so[0])
+        if N % 256 == 0 and M >= 1024 and it % 2 == 0:
+            # the LoRA down-projection in the 4-wave kernel's K loop (17th DMA piece, LDS image hand-over) vs the two-launch form
+            A16, B16r = rn(16, K) * 0.1, rn(N, 16) * 0.1
+            two = ops.linear(x, w, epilogue=ops.EPI_LORA, xa=ops.linear(x, A16), lora_b=B16r, lora_scale=1.0, resid=r)
+            check(f"gemm256 in-GEMM x.A^T M={M} N={N} K={K} it={it}", ops.linear_lora(x, w, A16, B16r, lora_scale=1.0, resid=r), two)
     print(f"gemm256 {M}x{N}x{K}: {REPS} runs done", flush=True)
 lib.dh_set_tuning(1, 5)
 for (M, N, K) in [(560, 2048, 2048), (560, 2560, 2048), (200, 512, 5632), (100, 128, 64)]:
