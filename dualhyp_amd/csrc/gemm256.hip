@@ -1,5 +1,12 @@
 // Large-M prefill GEMM: y[M,N] = epilogue(x[M,K] · W[N,K]^T), 256 x 256 x 64 block tiles.
 //
+// Two kernels share the tile walk, the chain (one fp32 accumulator per output, k ascending in steps of 32: bit-identical outputs) and
+// the epilogue function:
+//   gemm_nt256w4_kernel  (round 3, the default, dh_set_tuning(1, 5)): FOUR waves with 128 x 128 each, 64-deep full-line stages,
+//                        asm MFMAs with accumulators pinned to AGPRs, optional in-loop LoRA down-projection — described at the kernel;
+//   gemm_nt256_kernel    (rounds 1-2; now the fallback for K < 128 / operands >= 4 GiB and the A/B variants 1..4): EIGHT waves,
+//                        described in the rest of this header.
+//
 // Same orientation as gemm.hip (C^T tiles: A operand = W rows, B operand = x rows, a lane of the
 // accumulator owns 4 consecutive n of one m), but sized so the LDS read stream stops being the
 // limiter: a wave owns 128(n) x 64(m) = 8 x 4 tiles of v_mfma_f32_16x16x32_bf16, i.e. 12 ds_read_b128
@@ -957,8 +964,8 @@ int launch_one(const GemmArgs& a, hipStream_t s) {
 
 template <int EPI>
 int launch(const GemmArgs& a, hipStream_t s) {
-    // 1: ping-pong (default), 2: 4-stage pipeline with both waves of a SIMD in phase, 3: BK = 64 double buffer
-    // 4: persistent ping-pong where its loop-carried state fits the registers (the LoRA epilogues spill 47-116 VGPRs)
+    // 5 (default): the 4-wave full-line kernel; 8-wave kernel: 1 ping-pong, 2 4-stage pipeline with both waves of a SIMD in phase,
+    // 3 BK = 64 double buffer, 4 persistent ping-pong where its loop-carried state fits the registers (the LoRA epilogues spill 47-116 VGPRs)
     if (g_gemm_variant == 5 && w4_ok(a)) return a.resid ? launch_w4<EPI, true>(a, s) : launch_w4<EPI, false>(a, s);
     if (g_gemm_variant == 4 && (EPI == DH_EPI_PLAIN || EPI == DH_EPI_SWIGLU))
         return a.resid ? launch_one<EPI, true, 3>(a, s) : launch_one<EPI, false, 3>(a, s);
