@@ -257,6 +257,10 @@ __global__ __launch_bounds__(NW * 64, NW == 16 ? 1 : (NW == 6 ? 3 : (HS == 64 ? 
     }
 }
 
+// Round 3, one more shape measured and not kept (bit-identical, 82 tests green): every tile after a wave's first streamed through an 8-KiB LDS slot
+// private to the wave, filled by LDS-DMA one tile ahead with the second tile's request issued at kernel start (the wave's partial-O block
+// aliased into the slot: 69 KiB per block, two blocks per CU as before) — 4.71-4.73 ms per 640-row decode step against 4.58-4.64: the second
+// tile's exposed round trip is not what the kernel waits for.
 #ifndef DH_ATTN_WAVES64
 #define DH_ATTN_WAVES64 8     // A/B builds: 6 (two tiles in flight per wave) and 16 (one block per CU: measured 5.68 vs 4.74 ms per 640-row step)
 #endif
