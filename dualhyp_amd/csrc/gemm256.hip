@@ -651,7 +651,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt256_kernel(GemmArgs a) {
 // copies and does the same.  Memory operations do not cross a volatile asm, so the interleave in the source is the one issued.
 // DMA pieces use the saddr form of global_load_lds (uniform base + one 32-bit VGPR offset per piece): no 64-bit VALU address
 // arithmetic between the MFMAs.  (buffer_load ... lds through __builtin_amdgcn_raw_ptr_buffer_load_lds is not usable from
-// C++: the compiler then puts s_waitcnt vmcnt(0) in front of every ds_read that may alias the DMA's LDS destination.)
+// C++: the compiler then puts s_waitcnt vmcnt(0) in front of every ds_read that may alias the DMA's LDS destination; written as
+// asm — V# in SGPRs, SGPR byte offset, as the vendor library's kernel does — it measured 0-2 % slower than the saddr form.)
 // ---- the 4-wave kernel's schedule: slots 0..127 of an iteration (MFMA t of phase A is slot t, of phase B slot 64 + t)
 #ifndef DH_W4_RD1STEP
 #define DH_W4_RD1STEP 2      // a read of F1 behind every RD1STEP-th MFMA from slot 0
