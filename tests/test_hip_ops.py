@@ -203,6 +203,13 @@ def test_linear_lora_down_projection_in_the_gemm(dev, M):
     # attn.proj-shaped: one segment, fused residual, lora_scale 1 (its own code path in the epilogue)
     want = ops.linear(x, wp, epilogue=ops.EPI_LORA, xa=ops.linear(x, A16), lora_b=Bp, lora_scale=1.0, resid=res)
     assert torch.equal(ops.linear_lora(x, wp, A16, Bp, lora_scale=1.0, resid=res), want)
+    # with the 8-wave kernel selected the library must take the two-launch path by itself
+    from dualhyp_amd import _lib
+    try:
+        _lib.load().dh_set_tuning(1, 1)
+        assert torch.equal(ops.linear_lora(x, wp, A16, Bp, lora_scale=1.0, resid=res), want)
+    finally:
+        _lib.load().dh_set_tuning(1, 5)
     # segment boundaries off the 256-column grid: the library falls back to the separate launch
     want = ops.linear(x, w, epilogue=ops.EPI_LORA, xa=ops.linear(x, A48), lora_b=B16, lora_scale=2.0, splits=(d - 32, d + kv + 32))
     assert torch.equal(ops.linear_lora(x, w, A48, B16, lora_scale=2.0, splits=(d - 32, d + kv + 32)), want)
