@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""Top kernels of a rocprofv3 `--kernel-trace --stats --output-format csv` run: tools/top_kernels.py <kernel_stats.csv> [n] -> share, calls, average us, name."""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 for r in rows[:int(sys.argv[2]) if len(sys.argv) > 2 else 20]:
