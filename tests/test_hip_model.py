@@ -446,6 +446,45 @@ def test_relprompt_decoder_vs_reference(golden, name):
     assert torch.equal(got[: T + safe], t["bf16.generate_ids"][: T + safe])
 
 
+def test_relprompt_full_size_vs_reference(golden):
+    """BASELINE config 4's decoder at FULL size (tests/golden/relprompt_tinyllama: ger.relprompt.GPT with TinyLlama-1.1B's 22
+    layers and the GER LoRA set, nothing tied, wte grown by three rows, a 560-token prompt carrying 56 reliability tokens,
+    16 tokens by the reference's greedy loop).  Same gates as the untied benchmark-shape fixture: teacher-forced on the
+    reference's ids the arg-max agrees on every step the reference decides by >= 4 bf16 ulps, the logits are closer to
+    the reference's bf16 run than that run is to its own fp32 run, and the free-running ids equal the reference's inside
+    its tie-free prefix."""
+    from dualhyp_amd.relprompt import GPT as RelGPT
+    t, meta = golden("relprompt_tinyllama")
+    cfg, m = build(meta, cls=RelGPT, extra=True)
+    V = cfg.padded_vocab_size
+    m.resize_token_embeddings(3)
+    m.transformer.wte.weight.data[V:] = t["wte_extra_rows"].to(DEV)
+    m.refresh_engine()
+    T, G = meta["T"], meta["G"]
+    idx, ids, margins = t["idx"], t["generate_ids"], t["generate_margins_ulps"]
+    assert cfg.n_layer == 22 and T == 560 and int((idx >= V).sum()) == meta["reliability_tokens"] == 56
+    decided = margins >= SAFE_MARGIN_ULPS
+    got = _teacher_forced(m, idx, ids, T, G, fwd=lambda x, pos: m(x, input_pos=pos))
+    assert got.shape == (G, V)
+    agree = got.argmax(-1) == ids[T:T + G]
+    want, f32 = t["step_logits_v4096"].float(), t["step_logits_fp32_v4096"].float()
+    rr, yard = rel_rms(got[:, :4096], want), rel_rms(want, f32)
+    e_hip, e_ref = (got[:, :4096] - f32).abs().max().item(), (want - f32).abs().max().item()
+    top_u = ulp_diff(torch.gather(got, 1, t["step_top8_indices"]), t["step_top8_values"].float())
+    record_parity("relprompt_tinyllama.teacher_forced", steps=G, steps_decided_ge4ulp=int(decided.sum()),
+                  argmax_equal_on_decided_steps=int((agree & decided).sum()), argmax_equal_all_steps=int(agree.sum()),
+                  rel_rms_hip_vs_ref=rr, rel_rms_ref_vs_fp32=yard, max_abs_hip_vs_fp32=e_hip, max_abs_ref_vs_fp32=e_ref,
+                  top8_max_ulp=top_u.max().item(), bit_exact_frac_v4096=(got[:, :4096] == want).float().mean().item())
+    bad = (decided & ~agree).nonzero().flatten().tolist()
+    assert not bad, f"arg-max differs on steps the reference decides by >= 4 ulps: {bad}"
+    assert rr <= yard and e_hip <= 1.5 * e_ref
+    safe = G if bool(decided.all()) else int((~decided).nonzero()[0])
+    free = generate(m, idx.to(DEV), T + G, temperature=0.2, top_k=1).cpu()
+    n_eq = _equal_prefix(free[T:], ids[T:])
+    record_parity("relprompt_tinyllama.free_running", generated=G, reference_tie_free_prefix=safe, ids_equal_prefix=n_eq)
+    assert n_eq >= safe
+
+
 def test_llama3_8b_shape_vs_reference(golden):
     """BASELINE config 5's layer shape (Llama-3-8B, ger/config.py:801-818: d 4096, 32 heads / 8 groups, hs 128,
     I 14336, V 128256, LoRA r 16) with 2 layers, bf16: prefill + decode logits and greedy ids against the reference."""

@@ -310,6 +310,31 @@ def test_full_tinyllama_512_untied(golden):
 
 
 @SLOW
+def test_relprompt_full_size(golden):
+    """BASELINE config 4's decoder at full size (tests/golden/relprompt_tinyllama: ger.relprompt.GPT, 22 layers, 560-token
+    prompt with 56 reliability tokens): the oracle over the grown embedding table, teacher-forced on the reference's ids,
+    reproduces the reference's per-step logits and top-8 on all 16 steps."""
+    t, meta = golden("relprompt_tinyllama")
+    cfg = Config(**meta["config"])
+    sd = synth_state_dict(cfg, seed=meta["seed"])
+    sd["transformer.wte.weight"] = torch.cat([sd["transformer.wte.weight"], t["wte_extra_rows"]])
+    m = O.OracleGPT(cfg, sd)
+    T, G = meta["T"], meta["G"]
+    ids = t["generate_ids"]
+    assert int((t["idx"] >= cfg.padded_vocab_size).sum()) == meta["reliability_tokens"]
+    with torch.no_grad():
+        lg = [m(t["idx"].view(1, -1), torch.arange(T))[0, -1]]
+        for s in range(G - 1):
+            lg.append(m(ids[T + s].view(1, 1), torch.tensor([T + s]))[0, 0])
+    trace = torch.stack(lg)
+    assert trace.size(-1) == cfg.padded_vocab_size
+    _close(trace[:, :4096], t["step_logits_v4096"], torch.bfloat16, "step logits")
+    _close(torch.gather(trace.float(), 1, t["step_top8_indices"]), t["step_top8_values"].float(), torch.bfloat16, "top-8 values")
+    decided = t["generate_margins_ulps"] >= 4
+    assert bool((trace.argmax(-1) == ids[T:T + G])[decided].all())
+
+
+@SLOW
 def test_llama3_shape(golden):
     """BASELINE config 5's layer shape (Llama-3-8B: hs 128, 8 groups, I 14336, V 128256), 2 layers."""
     t, meta = golden("llama3_shape")
