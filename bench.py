@@ -68,15 +68,20 @@ MFMA_PEAK_TFLOPS = 2500.0     # bf16 dense, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
 
-def gemm_flops_per_prefill(cfg, n_tok: int, n_seq: int, merged_lora: bool = False) -> float:
-    """Algorithmic FLOPs of the M>32 GEMM launches of one packed prefill:
-    per layer qkv + proj + fc_1 + fc_2 + mlp proj on every token; LoRA rank-16 side products;
-    the lm_head runs on the last position only (M = n_seq <= 32: not in this class)."""
+def gemm_flops_per_prefill(cfg, n_tok: int, n_seq: int, merged_lora: bool = False, last_rows_only: bool = False) -> float:
+    """Algorithmic FLOPs of the GEMM launches of one packed prefill THAT ARE EXECUTED: per layer qkv + proj +
+    fc_1 + fc_2 + mlp proj on every token; LoRA rank-16 side products; the lm_head runs on the last position only (M = n_seq
+    <= 32: not in this class).  `last_rows_only` (the bf16 engine's prompt forward, csrc/engine.hip g_prune_last_layer): the
+    LAST block's proj / fc_1 / fc_2 / mlp proj run on the n_seq last rows, not on every token — those FLOPs are not counted."""
     d, I = cfg.n_embd, cfg.intermediate_size
     qkv = (cfg.n_head + 2 * cfg.n_query_groups) * cfg.head_size
     per_tok = 2 * d * (qkv + d + 3 * I)
     lora = (2 * d * (48 + 16) + 2 * 16 * (qkv + d)) if merged_lora is False else 0
-    return float(cfg.n_layer * n_tok * (per_tok + lora))
+    total = float(cfg.n_layer * n_tok * (per_tok + lora))
+    if last_rows_only:
+        tail = 2 * d * (d + 3 * I) + ((2 * d * 16 + 2 * 16 * d) if merged_lora is False else 0)   # per row of the last block after QKV
+        total -= float((n_tok - n_seq) * tail)
+    return total
 
 
 def decode_bytes_per_step(cfg, rows: float, mean_ctx: float, weight_bytes: int, merged_lora: bool) -> float:
@@ -297,7 +302,9 @@ def main() -> None:
     result = None
     if rank == 0:
         utt = B * a.steps * world
-        flops = gemm_flops_per_prefill(cfg, sum(p.numel() for p in timed_prompts), B * a.steps, merged_lora=wl["fp8"])
+        pruned = not wl["fp8"] and not any(kv.split("=")[0] == "23" and kv.split("=")[1] == "0" for kv in a.tune)
+        flops = gemm_flops_per_prefill(cfg, sum(p.numel() for p in timed_prompts), B * a.steps, merged_lora=wl["fp8"],
+                                       last_rows_only=pruned)
         achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         traffic = None   # HBM-side bytes per launch from the committed PMC passes
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_gemm_w4.json")
@@ -315,6 +322,8 @@ def main() -> None:
                        "parallelism": f"replicas x{world}", "batches_in_flight_per_gpu": G, "schedule": a.schedule,
                        "decode_rows_per_launch": B * min(G, a.steps) if a.schedule == "merged" else B,
                        "prefill_tokens_per_launch": B * PROMPT_LEN * (a.prefill_batches if a.schedule == "merged" else 1),
+                       "last_block_rows": "last token of each sequence (proj / MLP of the last block feed only the last-position logits; "
+                                          "K / V of every token are computed)" if pruned else "all",
                        **({"tuning": a.tune} if a.tune else {})},
             "roofline": {"bound": "mfma", "kernel": wl["kernel"],
                          "achieved": achieved, "peak": wl["peak"], "unit": "TFLOP/s",

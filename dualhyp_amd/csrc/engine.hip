@@ -28,6 +28,12 @@ constexpr int MAX_DECODE_ROWS = 2048;  // single-token calls up to here take the
 int g_decode_tiled_rows = 0;
 int g_short_kps = 8;       // k-steps per K-slice of the partial-sum GEMMs when K <= 4096 (dh_set_tuning key 16: 8 or 16)
 int g_fuse_qkv_rope = 1;   // dh_set_tuning key 12: 0 = QKV GEMM, then dh_qkv_rope_cache_bf16 (the two-step form)
+// dh_set_tuning key 23.  A prefill that is asked for the LAST position's logits only (generate's prompt forward,
+// generate/base.py:57-60: `logits[0, -1]`) needs, of the last layer, the K / V rows of every token (they go to the cache) but the
+// attention output, projection and MLP of the last token of each sequence alone: the other rows of the last block feed nothing
+// (the reference computes and drops them, as it does the lm_head rows — SURVEY Q9).  1 = run those four products on the
+// n_seq last rows (same kernels, same chains: the rows' bits do not change); 0 = on every row.
+int g_prune_last_layer = 1;
 
 struct dh_engine {
     dh_model_desc d;
@@ -40,6 +46,8 @@ struct dh_engine {
            *act = nullptr, *xlast = nullptr, *logits = nullptr;
     int32_t *tok_slot = nullptr, *tok_pos = nullptr, *seq_meta = nullptr;   // seq_meta: 4 x [B]
     int32_t *last_row = nullptr, *step_dev = nullptr;
+    int32_t* last_meta = nullptr;                       // [ones | position of the last token] x [B]: the pruned last layer's attention call
+    bf16_t *att_last = nullptr, *xn_last = nullptr, *act_last = nullptr;   // its n_seq-row operands
     uint8_t *row_tail = nullptr, *last_tail = nullptr, *ones = nullptr;   // Q11 rsqrt emulation flags
     int rsqrt_vec = 0, rsqrt_whole = 0;
     int64_t* dec_ids = nullptr;
@@ -137,7 +145,7 @@ int linear(dh_engine* e, const bf16_t* x, const bf16_t* w, bf16_t* y, int M, int
 // The layer stack on n_tok packed tokens whose metadata is already on the device.
 // prefill: attention over (seq_slot, q_start, q_len, kv_pos0); decode: one token per sequence.
 int run_layers(dh_engine* e, const int64_t* ids, int n_tok, int n_seq, int max_q_len, bool decode,
-               const uint8_t* tail_flags, hipStream_t s) {
+               const uint8_t* tail_flags, hipStream_t s, bool prune_last = false) {
     const uint8_t* rt = e->rsqrt_vec > 0 ? tail_flags : nullptr;
     e->phase_decode = decode;
     const dh_model_desc& D = e->d;
@@ -178,6 +186,35 @@ int run_layers(dh_engine* e, const int64_t* ids, int n_tok, int n_seq, int max_q
         }
         if ((rc = dh_qkv_rope_cache_bf16(e->qkv, D.rope_cos, D.rope_sin, e->tok_slot, e->tok_pos, e->qrot, kc, vtc, nullptr,
                                          nullptr, n_tok, H, G, hs, e->s_max, s))) return rc;
+        }
+        if (prune_last && l == D.n_layer - 1) {
+            // last block, last-position logits only: attention of each sequence's LAST query (a one-row tile at position
+            // pos0 + len - 1 over the same 64-key steps as in the full call), then projection, norm and MLP on n_seq rows.  The
+            // final hidden rows land in e->xlast (where the caller would have gathered them); e->x keeps this block's input.
+            const uint8_t* rtl = e->rsqrt_vec > 0 ? e->last_tail : nullptr;
+            {
+                TimeScope t(e, 2, s);
+                if ((rc = dh_attn_prefill_bf16(e->qrot, kc, vtc, seq_slot, e->last_row, e->last_meta, e->last_meta + e->max_batch,
+                                               e->att, nullptr, n_seq, 1, H, G, hs, e->s_max, s))) return rc;
+            }
+            hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(n_seq, 4)), dim3(256), 0, s, e->att, e->last_row, e->att_last, n_seq, d);
+            hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(n_seq, 4)), dim3(256), 0, s, e->x, e->last_row, e->xlast, n_seq, d);
+            DH_LAUNCH_CHECK();
+            // (these n_seq-row launches stream the weights; they are not in the timed class of the large prefill GEMMs, and
+            // bench.py does not count their FLOPs either)
+            if (W.proj_lora_a) {
+                if ((rc = dh_linear_lora_impl(e->att_last, W.proj_w, e->xlast, n_seq, d, d, W.proj_lora_a, W.proj_lora_b, D.lora_scale, d, d,
+                                              e->xlast, e->xa, 1, s))) return rc;
+            } else {
+                if ((rc = linear(e, e->att_last, W.proj_w, e->xlast, n_seq, d, d, DH_EPI_PLAIN, nullptr, nullptr, 0, nullptr, 0, 0,
+                                 nullptr, nullptr, e->xlast, s, false))) return rc;
+            }
+            if ((rc = dh_rmsnorm_bf16(e->xlast, nullptr, W.norm_2, e->xn_last, nullptr, n_seq, d, D.norm_eps, rtl, s))) return rc;
+            if ((rc = linear(e, e->xn_last, W.fc_1, e->act_last, n_seq, I, d, DH_EPI_SWIGLU, W.fc_2, nullptr, 0, nullptr, 0, 0, nullptr,
+                             nullptr, nullptr, s, false))) return rc;
+            if ((rc = linear(e, e->act_last, W.mlp_proj, e->xlast, n_seq, d, I, DH_EPI_PLAIN, nullptr, nullptr, 0, nullptr, 0, 0, nullptr,
+                             nullptr, e->xlast, s, false))) return rc;
+            break;
         }
         if (decode) {
             TimeScope t(e, 3, s);
@@ -426,6 +463,10 @@ int engine_init(dh_engine* e, const dh_model_desc* desc, int max_batch, int s_ma
     rc |= dmalloc(e, &e->tok_pos, T);
     rc |= dmalloc(e, &e->seq_meta, (size_t)4 * max_batch);
     rc |= dmalloc(e, &e->last_row, (size_t)max_batch);
+    rc |= dmalloc(e, &e->last_meta, (size_t)2 * max_batch);
+    rc |= dmalloc(e, &e->att_last, (size_t)max_batch * d);
+    rc |= dmalloc(e, &e->xn_last, (size_t)max_batch * d);
+    rc |= dmalloc(e, &e->act_last, (size_t)max_batch * desc->intermediate);
     rc |= dmalloc(e, &e->step_dev, 1);
     rc |= dmalloc(e, &e->dec_ids, (size_t)max_batch);
     rc |= dmalloc(e, &e->part32, (size_t)16 * (max_batch < 32 ? 32 : (max_batch < MAX_DECODE_ROWS ? max_batch : MAX_DECODE_ROWS)) * (e->qkv_dim + 48));
@@ -444,7 +485,7 @@ int engine_init(dh_engine* e, const dh_model_desc* desc, int max_batch, int s_ma
     DH_HIP(hipMemset(e->vtc, 0, e->cache_layer_elems * desc->n_layer * sizeof(bf16_t)));
     DH_HIP(hipMemset(e->step_dev, 0, sizeof(int32_t)));
     DH_HIP(hipMemset(e->ones, 1, (size_t)max_batch));
-    DH_HIP(hipHostMalloc((void**)&e->h_stage, (3 * T + 6 * (size_t)max_batch) * sizeof(int32_t)));
+    DH_HIP(hipHostMalloc((void**)&e->h_stage, (3 * T + 8 * (size_t)max_batch) * sizeof(int32_t)));
     DH_HIP(hipStreamCreateWithFlags(&e->gstream, hipStreamNonBlocking));
     DH_HIP(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
     DH_HIP(hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming));
@@ -460,7 +501,7 @@ extern "C" void dh_engine_destroy(dh_engine* e) {
     if (!e) return;
     for (auto& g : e->graphs) hipGraphExecDestroy(g.exec);
     void* ptrs[] = {e->kc, e->vtc, e->x, e->xn, e->qkv, e->qrot, e->att, e->xa, e->act, e->xlast, e->logits,
-                    e->tok_slot, e->tok_pos, e->seq_meta, e->last_row, e->step_dev, e->dec_ids, e->dec_work,
+                    e->tok_slot, e->tok_pos, e->seq_meta, e->last_row, e->last_meta, e->att_last, e->xn_last, e->act_last, e->step_dev, e->dec_ids, e->dec_work,
                     e->row_tail, e->last_tail, e->ones, e->part32, e->xq, e->xscale};
     for (void* p : ptrs)
         if (p) hipFree(p);
@@ -549,6 +590,13 @@ extern "C" int dh_engine_forward_at(dh_engine* e, const int64_t* ids, const int3
     // seq_meta[0..B) (slot of sequence i = i) is written once at engine creation and left alone
     DH_HIP(hipMemcpyAsync(e->seq_meta + B, h_meta + B, 3 * B * sizeof(int32_t), hipMemcpyHostToDevice, s));
     DH_HIP(hipMemcpyAsync(e->last_row, h_meta + 4 * B, B * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    // last-position logits of a multi-token forward only: the last block runs on the sequences' last rows (g_prune_last_layer)
+    const bool prune_last = g_prune_last_layer && !e->fp8 && max_q > 1 && logits_all == nullptr && logits_last != nullptr;
+    if (prune_last) {
+        int32_t* h_lm = hs_ + 3 * (size_t)e->max_tokens + 6 * (size_t)B;   // behind the tail flags
+        for (int i = 0; i < n_seq; ++i) { h_lm[i] = 1; h_lm[B + i] = h_pos0[i] + h_seq_len[i] - 1; }
+        DH_HIP(hipMemcpyAsync(e->last_meta, h_lm, 2 * B * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    }
     DH_HIP(hipEventRecord(e->ev_stage, s));
     int rc;
     // one token per sequence == a decode step (what generate()'s loop issues): same kernels as dh_engine_decode
@@ -573,8 +621,9 @@ extern "C" int dh_engine_forward_at(dh_engine* e, const int64_t* ids, const int3
         if (logits_last && (rc = head_normed(e, n_seq, logits_last, s))) return rc;
         return 0;
     }
-    if ((rc = run_layers(e, ids, n_tok, n_seq, max_q, max_q == 1, e->row_tail, s))) return rc;
+    if ((rc = run_layers(e, ids, n_tok, n_seq, max_q, max_q == 1, e->row_tail, s, prune_last))) return rc;
     e->last_ntok = n_tok;
+    if (prune_last) return head(e, e->xlast, n_seq, logits_last, e->last_tail, s);   // e->xlast: the last rows' final hidden state
     if (logits_all) {
         // ln_f output lands in e->xn (test hook dh_engine_hidden)
         if ((rc = head(e, e->x, n_tok, logits_all, e->row_tail, s))) return rc;

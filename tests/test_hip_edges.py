@@ -165,3 +165,50 @@ def test_ragged_batch_of_extremes(tiny):
         T = q.numel()
         record_parity(f"edges.ragged_len{T}", generated=new, tie_free_prefix=safe)
         assert torch.equal(a[:T + safe], w[:T + safe])
+
+
+@pytest.mark.parametrize("shape", ["tiny", "tinyllama-width"])
+def test_last_block_on_the_last_rows_only_changes_nothing(shape):
+    """A prefill asked for the last position's logits (generate's prompt forward, generate/base.py:57-60) runs the LAST
+    block's attention output, projection and MLP on each sequence's last row only (csrc/engine.hip g_prune_last_layer; the
+    K / V rows of every token still go to the cache).  Against the same call with every row computed (dh_set_tuning 23 = 0):
+    logits bit-equal, the whole KV cache bit-equal, the decode that follows identical — for a ragged pack, for a chunk that
+    continues a cached prefix, and at a width / row count that takes the 256-tile GEMMs."""
+    from dualhyp_amd import _lib
+    lib = _lib.load()
+    if shape == "tiny":
+        cfg = Config.from_name("parity-tiny", r=4, alpha=8, dropout=0.0, to_query=True, to_key=True, to_value=True, to_projection=True)
+        lens = [1, 2, 31, 32, 33, 64, 65, 97, 120]
+    else:      # TinyLlama's layer shape (d 2048, 32 heads / 4 groups, I 5632), 2 layers, 2 x 700 + 1 rows: the 256-tile kernels
+        cfg = Config.from_name("tiny-llama-1.1b-chat", r=16, alpha=16, dropout=0.0, to_query=True, to_key=True, to_value=True,
+                               to_projection=True, n_layer=2)
+        lens = [700, 1, 700]
+    sd = synth_state_dict(cfg, seed=11, norm_jitter=0.25, weight_scale=4.0 if shape == "tiny" else 1.0, device=DEV)
+    m = GPT(cfg).to(device=DEV, dtype=torch.bfloat16)
+    m.load_state_dict(sd)
+    m.eval()
+    ps = [synth_prompts(1, n, cfg.padded_vocab_size, seed=200 + i)[0].to(DEV) for i, n in enumerate(lens)]
+    packed = torch.cat(ps)
+    S = 128 if shape == "tiny" else 768
+    G, hs, L = cfg.n_query_groups, cfg.head_size, cfg.n_layer
+
+    def run(prune: int):
+        _lib.check(lib.dh_set_tuning(23, prune))
+        m.refresh_engine()          # a fresh (zeroed) KV cache for each run: the caches are compared whole
+        try:
+            eng = m.engine(len(ps), S, int(packed.numel()), exact=True)
+            _, last = eng.forward(packed, lens, [0] * len(ps), want_all=False, want_last=True)
+            kv = [eng.read(w, l, (len(ps), G, S, hs)).clone() for l in range(L) for w in (1, 2)]
+            # a second chunk on top of the cached prefix of the first two sequences (chunked prefill), last logits only
+            more = [synth_prompts(1, 5, cfg.padded_vocab_size, seed=300 + i)[0].to(DEV) for i in range(2)]
+            _, last2 = eng.forward(torch.cat(more), [5, 5], lens[:2], want_all=False, want_last=True)
+            ids = generate_batch(m, ps, 6, temperature=0.2, top_k=1, prefill_batch=4)
+            return last.clone(), last2.clone(), kv, [o.cpu() for o in ids]
+        finally:
+            _lib.check(lib.dh_set_tuning(23, 1))
+
+    full, pruned = run(0), run(1)
+    assert torch.equal(full[0], pruned[0]), "last-position logits differ"
+    assert torch.equal(full[1], pruned[1]), "last-position logits of the continued chunk differ"
+    assert all(torch.equal(a, b) for a, b in zip(full[2], pruned[2])), "KV cache differs"
+    assert all(torch.equal(a, b) for a, b in zip(full[3], pruned[3])), "generated ids differ"
