@@ -72,7 +72,8 @@ def gemm_flops_per_prefill(cfg, n_tok: int, n_seq: int, merged_lora: bool = Fals
     """Algorithmic FLOPs of the GEMM launches of one packed prefill THAT ARE EXECUTED: per layer qkv + proj +
     fc_1 + fc_2 + mlp proj on every token; LoRA rank-16 side products; the lm_head runs on the last position only (M = n_seq
     <= 32: not in this class).  `last_rows_only` (the bf16 engine's prompt forward, csrc/engine.hip g_prune_last_layer): the
-    LAST block's proj / fc_1 / fc_2 / mlp proj run on the n_seq last rows, not on every token — those FLOPs are not counted."""
+    LAST block's proj / fc_1 / fc_2 / mlp proj run on the n_seq last rows only, as small weight-streaming launches OUTSIDE the
+    timed class: neither the skipped rows' FLOPs nor those launches' FLOPs are counted."""
     d, I = cfg.n_embd, cfg.intermediate_size
     qkv = (cfg.n_head + 2 * cfg.n_query_groups) * cfg.head_size
     per_tok = 2 * d * (qkv + d + 3 * I)
@@ -80,7 +81,7 @@ def gemm_flops_per_prefill(cfg, n_tok: int, n_seq: int, merged_lora: bool = Fals
     total = float(cfg.n_layer * n_tok * (per_tok + lora))
     if last_rows_only:
         tail = 2 * d * (d + 3 * I) + ((2 * d * 16 + 2 * 16 * d) if merged_lora is False else 0)   # per row of the last block after QKV
-        total -= float((n_tok - n_seq) * tail)
+        total -= float(n_tok * tail)
     return total
 
 
