@@ -41,7 +41,8 @@ int dh_abi_version(void);
  * kernel above 128 rows (0 = by grid size, 8, 10); 15 8-wave SwiGLU tile in gemm_dt (0 = from 256 rows, 1 always,
  * -1 never); 16 k-steps per K-slice for K <= 4096 (8 or 16); 17 / 18 / 21 pair-sum decode GEMM (tile width, first row count, sc1 stores);
  * 19 / 20 fp8 tile edge and band height; 22 persistent blocks of the 4-wave prefill GEMM (0 never, 1 where the epilogue loads nothing: default,
- * 2 always). */
+ * 2 always); 23 a forward asked for the last position's logits only runs the last block's attention output, projection and MLP on each
+ * sequence's last row (1, default) or on every row (0) — same bits either way (dh_engine_forward). */
 int dh_set_tuning(int key, int value);
 const char* dh_last_error(void);
 /* Name of the first visible device's gcnArch ("gfx950") into buf; fails when no GPU. */
@@ -380,7 +381,11 @@ int64_t dh_engine_device_bytes(const dh_engine* e);
  *   h_seq_len[i] tokens for slot i (i < n_seq) starting at cache position h_pos0[i];
  *   ids: packed [sum(seq_len)] int64 on device.
  * logits_all != NULL : [n_tok, vocab] logits of every position (reference behaviour, Q9)
- * logits_last != NULL: [n_seq, vocab] logits of each sequence's last position only. */
+ * logits_last != NULL: [n_seq, vocab] logits of each sequence's last position only.  With logits_all == NULL (generate's
+ *   prompt forward reads `logits[0, -1]`, generate/base.py:57-60) the last block's attention output, projection and MLP run on
+ *   those n_seq rows alone — K and V of every token still go to the cache; the logits and the caches are bit-equal to the
+ *   all-rows run (dh_set_tuning key 23; tests/test_hip_edges.py).  The hidden rows dh_engine_read(3) returns are then those
+ *   of the last block's INPUT. */
 int dh_engine_forward(dh_engine* e, const int64_t* ids, const int32_t* h_seq_len,
                       const int32_t* h_pos0, int n_seq, dh_bf16* logits_all,
                       dh_bf16* logits_last, void* stream);
