@@ -71,7 +71,7 @@ HBM_PEAK_GBS = 8000.0
 def gemm_flops_per_prefill(cfg, n_tok: int, n_seq: int, merged_lora: bool = False, last_rows_only: bool = False) -> float:
     """Algorithmic FLOPs of the GEMM launches of one packed prefill THAT ARE EXECUTED: per layer qkv + proj +
     fc_1 + fc_2 + mlp proj on every token; LoRA rank-16 side products; the lm_head runs on the last position only (M = n_seq
-    <= 32: not in this class).  `last_rows_only` (the bf16 engine's prompt forward, csrc/engine.hip g_prune_last_layer): the
+    <= 32: not in this class).  `last_rows_only` (the engine's prompt forward, csrc/engine.hip g_prune_last_layer): the
     LAST block's proj / fc_1 / fc_2 / mlp proj run on the n_seq last rows only, as small weight-streaming launches OUTSIDE the
     timed class: neither the skipped rows' FLOPs nor those launches' FLOPs are counted."""
     d, I = cfg.n_embd, cfg.intermediate_size
@@ -303,7 +303,7 @@ def main() -> None:
     result = None
     if rank == 0:
         utt = B * a.steps * world
-        pruned = not wl["fp8"] and not any(kv.split("=")[0] == "23" and kv.split("=")[1] == "0" for kv in a.tune)
+        pruned = not any(kv.split("=")[0] == "23" and kv.split("=")[1] == "0" for kv in a.tune)
         flops = gemm_flops_per_prefill(cfg, sum(p.numel() for p in timed_prompts), B * a.steps, merged_lora=wl["fp8"],
                                        last_rows_only=pruned)
         achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0

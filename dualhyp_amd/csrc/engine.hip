@@ -253,7 +253,7 @@ inline int fp8_kernel(bool decode, int rows) { return decode && rows <= 128 ? 2 
 // output; LoRA is merged into the weights before quantisation, so there is no rank-16 side product.  Prefill and
 // decode run the same sequence; the GEMM kernel is pinned by phase (fp8_kernel above).
 int run_layers_fp8(dh_engine* e, const int64_t* ids, int n_tok, int n_seq, int max_q_len, bool decode,
-                   const uint8_t* tail_flags, hipStream_t s) {
+                   const uint8_t* tail_flags, hipStream_t s, bool prune_last = false) {
     const uint8_t* rt = e->rsqrt_vec > 0 ? tail_flags : nullptr;
     e->phase_decode = decode;
     const dh_model_desc& D = e->d;
@@ -294,6 +294,31 @@ int run_layers_fp8(dh_engine* e, const int64_t* ids, int n_tok, int n_seq, int m
         }
         if ((rc = dh_qkv_rope_cache_bf16(e->qkv, D.rope_cos, D.rope_sin, e->tok_slot, e->tok_pos, e->qrot, kc, vtc, nullptr,
                                          nullptr, n_tok, H, G, hs, e->s_max, s))) return rc;
+        if (prune_last && l == D.n_layer - 1) {
+            // last block of a prompt forward that wants the last position's logits only: see run_layers.  The products stay on the
+            // phase's (tiled) kernel and the activations are quantised per row, so the n_seq rows keep their bits.
+            const uint8_t* rtl = e->rsqrt_vec > 0 ? e->last_tail : nullptr;
+            auto lin_last = [&](const bf16_t* w, const float* ws, bf16_t* y, int N, int K, int epi, const bf16_t* w2, const float* w2s,
+                                const bf16_t* res) {
+                return dh_linear_fp8_ex(e->xq, e->xscale, reinterpret_cast<const uint8_t*>(w), ws, y, n_seq, N, K, epi,
+                                        reinterpret_cast<const uint8_t*>(w2), w2s, nullptr, nullptr, res, fp8_kernel(false, n_seq), s);
+            };
+            {
+                TimeScope t(e, 2, s);
+                if ((rc = dh_attn_prefill_bf16(e->qrot, kc, vtc, seq_slot, e->last_row, e->last_meta, e->last_meta + e->max_batch,
+                                               e->att, nullptr, n_seq, 1, H, G, hs, e->s_max, s))) return rc;
+            }
+            hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(n_seq, 4)), dim3(256), 0, s, e->att, e->last_row, e->att_last, n_seq, d);
+            hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(n_seq, 4)), dim3(256), 0, s, e->x, e->last_row, e->xlast, n_seq, d);
+            DH_LAUNCH_CHECK();
+            if ((rc = dh_quant_rows_fp8(e->att_last, e->xq, e->xscale, n_seq, d, s))) return rc;
+            if ((rc = lin_last(W.proj_w, W.proj_ws, e->xlast, d, d, DH_EPI_PLAIN, nullptr, nullptr, e->xlast))) return rc;
+            if ((rc = dh_rmsnorm_quant_fp8(e->xlast, W.norm_2, nullptr, e->xq, e->xscale, n_seq, d, D.norm_eps, rtl, s))) return rc;
+            if ((rc = lin_last(W.fc_1, W.fc_1_ws, e->act_last, I, d, DH_EPI_SWIGLU, W.fc_2, W.fc_2_ws, nullptr))) return rc;
+            if ((rc = dh_quant_rows_fp8(e->act_last, e->xq, e->xscale, n_seq, I, s))) return rc;
+            if ((rc = lin_last(W.mlp_proj, W.mlp_proj_ws, e->xlast, d, I, DH_EPI_PLAIN, nullptr, nullptr, e->xlast))) return rc;
+            break;
+        }
         if (decode) {
             TimeScope t(e, 3, s);
             if ((rc = dh_attn_decode_bf16(e->qrot, kc, vtc, seq_slot, kv_pos0, e->att, e->dec_work, n_seq, H, G, hs,
@@ -591,7 +616,7 @@ extern "C" int dh_engine_forward_at(dh_engine* e, const int64_t* ids, const int3
     DH_HIP(hipMemcpyAsync(e->seq_meta + B, h_meta + B, 3 * B * sizeof(int32_t), hipMemcpyHostToDevice, s));
     DH_HIP(hipMemcpyAsync(e->last_row, h_meta + 4 * B, B * sizeof(int32_t), hipMemcpyHostToDevice, s));
     // last-position logits of a multi-token forward only: the last block runs on the sequences' last rows (g_prune_last_layer)
-    const bool prune_last = g_prune_last_layer && !e->fp8 && max_q > 1 && logits_all == nullptr && logits_last != nullptr;
+    const bool prune_last = g_prune_last_layer && max_q > 1 && logits_all == nullptr && logits_last != nullptr;
     if (prune_last) {
         int32_t* h_lm = hs_ + 3 * (size_t)e->max_tokens + 6 * (size_t)B;   // behind the tail flags
         for (int i = 0; i < n_seq; ++i) { h_lm[i] = 1; h_lm[B + i] = h_pos0[i] + h_seq_len[i] - 1; }
@@ -602,8 +627,9 @@ extern "C" int dh_engine_forward_at(dh_engine* e, const int64_t* ids, const int3
     // one token per sequence == a decode step (what generate()'s loop issues): same kernels as dh_engine_decode
     e->decode_tiled = max_q == 1 && g_decode_tiled_rows > 0 && n_seq >= g_decode_tiled_rows;
     if (e->fp8) {
-        if ((rc = run_layers_fp8(e, ids, n_tok, n_seq, max_q, max_q == 1, e->row_tail, s))) return rc;
+        if ((rc = run_layers_fp8(e, ids, n_tok, n_seq, max_q, max_q == 1, e->row_tail, s, prune_last))) return rc;
         e->last_ntok = n_tok;
+        if (prune_last) return head_fp8(e, e->xlast, n_seq, logits_last, e->last_tail, s);
         if (logits_all && (rc = head_fp8(e, e->x, n_tok, logits_all, e->row_tail, s))) return rc;
         if (logits_last) {
             hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(n_seq, 4)), dim3(256), 0, s, e->x, e->last_row, e->xlast, n_seq,

@@ -167,7 +167,7 @@ def test_ragged_batch_of_extremes(tiny):
         assert torch.equal(a[:T + safe], w[:T + safe])
 
 
-@pytest.mark.parametrize("shape", ["tiny", "tinyllama-width"])
+@pytest.mark.parametrize("shape", ["tiny", "tiny-fp8", "tinyllama-width"])
 def test_last_block_on_the_last_rows_only_changes_nothing(shape):
     """A prefill asked for the last position's logits (generate's prompt forward, generate/base.py:57-60) runs the LAST
     block's attention output, projection and MLP on each sequence's last row only (csrc/engine.hip g_prune_last_layer; the
@@ -179,17 +179,23 @@ def test_last_block_on_the_last_rows_only_changes_nothing(shape):
     if shape == "tiny":
         cfg = Config.from_name("parity-tiny", r=4, alpha=8, dropout=0.0, to_query=True, to_key=True, to_value=True, to_projection=True)
         lens = [1, 2, 31, 32, 33, 64, 65, 97, 120]
+    elif shape == "tiny-fp8":      # the fp8 serving engine (merged LoRA, e4m3 weights): run_layers_fp8 takes the same short cut
+        cfg = Config.from_name("parity-hs128", r=16, alpha=16, dropout=0.0, to_query=True, to_key=True, to_value=True, to_projection=True)
+        lens = [1, 2, 31, 32, 33, 64, 65, 97, 120]
     else:      # TinyLlama's layer shape (d 2048, 32 heads / 4 groups, I 5632), 2 layers, 2 x 700 + 1 rows: the 256-tile kernels
         cfg = Config.from_name("tiny-llama-1.1b-chat", r=16, alpha=16, dropout=0.0, to_query=True, to_key=True, to_value=True,
                                to_projection=True, n_layer=2)
         lens = [700, 1, 700]
-    sd = synth_state_dict(cfg, seed=11, norm_jitter=0.25, weight_scale=4.0 if shape == "tiny" else 1.0, device=DEV)
+    sd = synth_state_dict(cfg, seed=11, norm_jitter=0.25, weight_scale=4.0 if shape.startswith("tiny") and "llama" not in shape else 1.0, device=DEV)
     m = GPT(cfg).to(device=DEV, dtype=torch.bfloat16)
     m.load_state_dict(sd)
     m.eval()
+    if shape == "tiny-fp8":
+        from dualhyp_amd import quantize_model_fp8
+        quantize_model_fp8(m)
     ps = [synth_prompts(1, n, cfg.padded_vocab_size, seed=200 + i)[0].to(DEV) for i, n in enumerate(lens)]
     packed = torch.cat(ps)
-    S = 128 if shape == "tiny" else 768
+    S = 768 if shape == "tinyllama-width" else 128
     G, hs, L = cfg.n_query_groups, cfg.head_size, cfg.n_layer
 
     def run(prune: int):
