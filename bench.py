@@ -436,7 +436,7 @@ def bench_finetune(a, wl, cfg, model, dev, rank: int, world: int, rehearsal: boo
         losses = []
         for i in range(per_rank // PACK):
             j = (k * (per_rank // PACK) + i) % len(mine)
-            losses.append(step_fn(mine[j], labs[j], 1.0 / per_rank))   # mean over this rank's micro-batches; all_reduce_mean then averages the ranks (as fit() does)
+            losses.append(step_fn(mine[j], labs[j], 1.0 / per_rank, n_targets=PACK * (T - 512)))   # mean over this rank's micro-batches; all_reduce_mean then averages the ranks (as fit() does)
         bucket.all_reduce_mean()
         opt.step()
         bucket.zero()
@@ -461,10 +461,13 @@ def bench_finetune(a, wl, cfg, model, dev, rank: int, world: int, rehearsal: boo
         # fwd 2NT + dX 2NT over the frozen base (no dW), LoRA 6 x 4.5M x T, attention fwd+bwd
         d, I = cfg.n_embd, cfg.intermediate_size
         qkv = (cfg.n_head + 2 * cfg.n_query_groups) * cfg.head_size
-        n_lin = cfg.n_layer * d * (qkv + d + 3 * I) + cfg.padded_vocab_size * d
+        n_lin = cfg.n_layer * d * (qkv + d + 3 * I)
         n_lora = cfg.n_layer * (64 * d + 16 * (qkv + d))
         attn = 3.5 * cfg.n_layer * 4 * cfg.n_head * cfg.head_size * (T * (T + 1) / 2)
-        flop_utt = 4.0 * n_lin * T + 6.0 * n_lora * T + attn
+        # the lm_head (forward + dX) runs on the rows that carry a target, in whole 128-row tiles per packed launch
+        # (train.GraphedTrainStep): EXECUTED FLOPs, not the T rows the reference pushes through it
+        head_rows = max(128, -(-(PACK * (T - 512)) // 128) * 128) / PACK
+        flop_utt = 4.0 * n_lin * T + 4.0 * cfg.padded_vocab_size * d * head_rows + 6.0 * n_lora * T + attn
         utt = GLOBAL * a.steps
         achieved = flop_utt * utt / dt / 1e12 / world          # per GPU
         emit({

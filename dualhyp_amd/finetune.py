@@ -189,7 +189,8 @@ def fit(model, train_examples: Sequence[Dict[str, torch.Tensor]], collate: Calla
         exs = [ex for _, ex in pending]
         batch = collate(exs)
         losses = packed(batch["input_ids"].to(device), batch["labels"].to(device), 1.0 / accum,
-                        lengths=[int(ex["input_ids"].numel()) for ex in exs])
+                        lengths=[int(ex["input_ids"].numel()) for ex in exs],
+                        n_targets=int((batch["labels"][:, 1:] != -1).sum()))      # counted on the host copy: no device sync
         loss_acc += losses.sum()
         if on_micro is not None:
             for k, (it_k, _) in enumerate(pending):

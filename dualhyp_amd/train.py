@@ -177,11 +177,13 @@ class _DecoderFn(torch.autograd.Function):
             x = ops.linear(L.act, blk.mlp.proj.linear.weight.data, resid=L.x1)
             saved.append(L)
         xf = ops.rmsnorm(x, model.transformer.ln_f.weight.data, cfg.norm_eps, row_tail=tail)
-        logits = ops.linear(xf, model.lm_head.linear.weight.data, epilogue=ops.EPI_ADAPTER,
-                            scale=model.lm_head.adapter_scale.data, bias=model.lm_head.adapter_bias.data)
         ctx.model, ctx.saved, ctx.x_last = model, saved, x
         ctx.meta = (B, T, cos, sin, tok_pos, q_start, q_len)
         ctx.param_dtypes = [p.dtype for p in lora_ps]
+        if getattr(ctx, "hidden_only", False):      # GraphedTrainStep: lm_head + loss on the rows that carry a target only
+            return xf
+        logits = ops.linear(xf, model.lm_head.linear.weight.data, epilogue=ops.EPI_ADAPTER,
+                            scale=model.lm_head.adapter_scale.data, bias=model.lm_head.adapter_bias.data)
         return logits.view(B, T, -1)
 
     @staticmethod
@@ -192,12 +194,15 @@ class _DecoderFn(torch.autograd.Function):
         d, H, G, hs, I = cfg.n_embd, cfg.n_head, cfg.n_query_groups, cfg.head_size, cfg.intermediate_size
         fz = _frozen(model)
         dev = dlogits.device
-        dz = dlogits.reshape(B * T, -1).to(BF)
-        scale_vec = model.lm_head.adapter_scale.data
-        if not fz.scale_is_one:                                        # (frozen: checked once, no host sync here)
-            dz = dz * scale_vec                                        # d(scale*(z+bias))/dz
-        dz = dz.contiguous()
-        dxf = ops.linear(dz, fz.lm_T)
+        if getattr(ctx, "hidden_only", False):
+            dxf = dlogits                                                  # already d loss / d ln_f(x), [B*T, d]
+        else:
+            dz = dlogits.reshape(B * T, -1).to(BF)
+            scale_vec = model.lm_head.adapter_scale.data
+            if not fz.scale_is_one:                                        # (frozen: checked once, no host sync here)
+                dz = dz * scale_vec                                        # d(scale*(z+bias))/dz
+            dz = dz.contiguous()
+            dxf = ops.linear(dz, fz.lm_T)
         dx = ops.rmsnorm_bwd(dxf, ctx.x_last, model.transformer.ln_f.weight.data, cfg.norm_eps)
         grads: List[Optional[torch.Tensor]] = []
         per_layer: List[List[Optional[torch.Tensor]]] = []
@@ -309,24 +314,38 @@ class GraphedTrainStep:
     def _body(self, st) -> None:
         model, V = self.model, self.model.config.padded_vocab_size
         ctx = _Ctx()
+        ctx.hidden_only = True
         model._row_tail_override = st["tail"] if model.cpu_rsqrt_vec_width else None
         try:
-            logits = _DecoderFn.forward(ctx, model, st["ids"], *self.params)
+            xf = _DecoderFn.forward(ctx, model, st["ids"], *self.params)        # ln_f(x) of every row, [P * T_pad, d]
         finally:
             model._row_tail_override = None
-        lg = logits.view(-1, V)
-        per, lse = ops.cross_entropy_fwd(lg, st["targets"])
+        # lm_head, cross entropy and their backward on the rows that carry a target (`rows`: those first, in order, then ignored
+        # rows up to a static count).  A row without a target has loss 0 and a zero logit gradient (ignore_index = -1,
+        # ger/utils.py:424-463), so the scattered results are bit for bit what the all-rows pass produced — the fine-tune data
+        # label only the response (~50 of ~560 positions), and the V = 32000 head is the widest product of the step.
+        rows = st["rows"]
+        fz = _frozen(model)
+        lg = ops.linear(xf.index_select(0, rows), model.lm_head.linear.weight.data, epilogue=ops.EPI_ADAPTER,
+                        scale=model.lm_head.adapter_scale.data, bias=model.lm_head.adapter_bias.data)
+        tg_c = st["targets"].index_select(0, rows)
+        per_c, lse = ops.cross_entropy_fwd(lg, tg_c)
+        per = torch.zeros_like(st["grow"]).index_copy_(0, rows, per_c.to(torch.float32))
         st["loss"].copy_(per.view(st["ids"].size(0), -1).sum(1) * st["inv_count"])
-        dlogits = ops.cross_entropy_bwd(lg, st["targets"], lse, st["grow"])
-        grads = _DecoderFn.backward(ctx, dlogits.view(logits.shape))[2:]
+        dz = ops.cross_entropy_bwd(lg, tg_c, lse, st["grow"].index_select(0, rows)).to(BF)
+        if not fz.scale_is_one:
+            dz = dz * model.lm_head.adapter_scale.data
+        dxf = torch.zeros_like(xf).index_copy_(0, rows, ops.linear(dz.contiguous(), fz.lm_T))
+        grads = _DecoderFn.backward(ctx, dxf)[2:]
         off = 0
         for p, g in zip(self.params, grads):
             self.bucket.flat[off:off + p.numel()].add_(g.reshape(-1).to(torch.float32))
             off += p.numel()
 
-    def _state(self, P: int, T_pad: int, dev):
+    def _state(self, P: int, T_pad: int, dev, n_rows: int):
         n = P * T_pad
-        st = dict(ids=torch.zeros((P, T_pad), dtype=torch.int64, device=dev),
+        st = dict(rows=torch.arange(n_rows, dtype=torch.int64, device=dev),
+                  ids=torch.zeros((P, T_pad), dtype=torch.int64, device=dev),
                   targets=torch.full((n,), -1, dtype=torch.int64, device=dev),
                   grow=torch.zeros(n, dtype=torch.float32, device=dev),
                   tail=torch.zeros(n, dtype=torch.uint8, device=dev),
@@ -336,7 +355,7 @@ class GraphedTrainStep:
 
     @torch.no_grad()
     def __call__(self, input_ids: torch.Tensor, labels: torch.Tensor, loss_scale: float = 1.0,
-                 lengths: Optional[Sequence[int]] = None) -> torch.Tensor:
+                 lengths: Optional[Sequence[int]] = None, n_targets: Optional[int] = None) -> torch.Tensor:
         """input_ids / labels [P, T] (right-padded: ids 0, labels -1), `lengths` the true lengths (default T for all).
         -> the P micro-steps' losses (device tensor [P], finetune/ger.py:278-281); d(loss_scale * sum of them) is ADDED to
         the bucket."""
@@ -347,13 +366,20 @@ class GraphedTrainStep:
         T_pad = -(-max(lengths) // self.pad_to) * self.pad_to
         dev = input_ids.device
         Vw = self.model.cpu_rsqrt_vec_width
-        gkey = (P, T_pad, Vw)        # the rsqrt-emulation switch is resolved while capturing: part of the key
+        # rows that carry a target (labels[:, 1:] != -1 below the sequence's end): the caller's count when it knows it (no host
+        # sync), else counted here; rounded up to whole 128-row tiles — the head's GEMM stays in the tiled class whatever the count
+        W = min(T, T_pad)
+        if n_targets is None:
+            lens_h = torch.tensor(lengths, device=labels.device).view(-1, 1)
+            colh = torch.arange(1, W, device=labels.device).view(1, -1)
+            n_targets = int(((labels[:, 1:W] != -1) & (colh < lens_h)).sum())
+        n_rows = min(P * T_pad, max(128, -(-int(n_targets) // 128) * 128))
+        gkey = (P, T_pad, Vw, n_rows)        # the rsqrt-emulation switch is resolved while capturing: part of the key
         ent = self._graphs.get(gkey)
         if ent is None:
-            st = self._state(P, T_pad, dev)
+            st = self._state(P, T_pad, dev, n_rows)
             ent = self._graphs[gkey] = [st, None]
         st = ent[0]
-        W = min(T, T_pad)
         st["ids"].zero_()
         st["ids"][:, :W].copy_(input_ids[:, :W])
         tg = st["targets"].view(P, T_pad)
@@ -364,6 +390,8 @@ class GraphedTrainStep:
         col = torch.arange(T_pad, device=dev).view(1, -1)
         tg.masked_fill_(col >= (lens_d.view(-1, 1) - 1), -1)
         st["ids"].masked_fill_(col >= lens_d.view(-1, 1), 0)
+        # target rows first (stable: in order), ignored rows behind them; the first n_rows of that order go through the head
+        st["rows"].copy_(torch.sort((st["targets"] < 0).to(torch.int8), stable=True).indices[:n_rows])
         inv = 1.0 / (lens_d - 1).clamp_min(1).to(torch.float32)
         st["inv_count"].copy_(inv)
         st["grow"].view(P, T_pad).copy_((inv * loss_scale).view(-1, 1).expand(P, T_pad))
