@@ -76,7 +76,7 @@ def generate_batch(model: GPT, prompts: Sequence[torch.Tensor], max_new_tokens: 
         n = min(length_h[i], lens[i] + max_new_tokens)
         if done_h[i] == 1:
             n -= 1                      # generate/base.py:80 returns idx[:input_pos]: EOS excluded
-        out.append(tokens[i, :n].clone())
+        out.append(tokens[i, :n])       # a view of this call's own buffer (640 clone launches per 20-batch group otherwise)
     if return_state:
         return out, dict(tokens=tokens, length=length, done=done)
     return out
