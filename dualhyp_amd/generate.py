@@ -16,6 +16,9 @@ from . import ops
 from .gpt import GPT
 
 
+EOS_CHECK_EVERY = 16     # decode steps between two "has every sequence finished" read-backs (generate_batch with an eos_id)
+
+
 @torch.inference_mode()
 def generate_batch(model: GPT, prompts: Sequence[torch.Tensor], max_new_tokens: int, *, temperature: float = 1.0,
                    top_k: Optional[int] = None, eos_id: Optional[int] = None, seed: int = 1337,
@@ -59,8 +62,22 @@ def generate_batch(model: GPT, prompts: Sequence[torch.Tensor], max_new_tokens: 
     ops.sample(last, tokens, length, done, temperature=temperature, top_k=top_k, eos_id=eos_id, seed=seed, step=0)
     if ev:
         ev[1].record()
+    steps_run = 0
     if max_new_tokens > 1:
-        eng.decode(tokens, length, done, max_new_tokens - 1, temperature, top_k, eos_id, seed, first_step=0)
+        n = max_new_tokens - 1
+        if eos_id is None:
+            eng.decode(tokens, length, done, n, temperature, top_k, eos_id, seed, first_step=0)
+            steps_run = n
+        else:
+            # with an EOS the loop is issued EOS_CHECK_EVERY steps at a time and ends once every sequence has finished
+            # (generate/base.py:79-80 returns at the EOS; the harness asks for up to 150 tokens, inference/ger.py:71, and a
+            # correction is usually 20-40): one 4-byte read-back per chunk instead of up to 5x the steps
+            while steps_run < n:
+                c = min(EOS_CHECK_EVERY, n - steps_run)
+                eng.decode(tokens, length, done, c, temperature, top_k, eos_id, seed, first_step=steps_run)
+                steps_run += c
+                if steps_run < n and bool((done != 0).all()):
+                    break
     if ev:
         ev[2].record()
     model._cache_len = []  # slots now hold these sequences; a later cached forward must start at 0
@@ -69,8 +86,8 @@ def generate_batch(model: GPT, prompts: Sequence[torch.Tensor], max_new_tokens: 
     if ev:   # the read-back above has synchronised the stream
         timing["prefill_ms"] = timing.get("prefill_ms", 0.0) + ev[0].elapsed_time(ev[1])
         timing["decode_ms"] = timing.get("decode_ms", 0.0) + ev[1].elapsed_time(ev[2])
-        timing["decode_steps"] = timing.get("decode_steps", 0) + max_new_tokens - 1
-        timing["decode_row_steps"] = timing.get("decode_row_steps", 0) + B * (max_new_tokens - 1)
+        timing["decode_steps"] = timing.get("decode_steps", 0) + steps_run
+        timing["decode_row_steps"] = timing.get("decode_row_steps", 0) + B * steps_run
     out: List[torch.Tensor] = []
     for i in range(B):
         n = min(length_h[i], lens[i] + max_new_tokens)

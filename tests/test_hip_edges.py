@@ -218,3 +218,43 @@ def test_last_block_on_the_last_rows_only_changes_nothing(shape):
     assert torch.equal(full[1], pruned[1]), "last-position logits of the continued chunk differ"
     assert all(torch.equal(a, b) for a, b in zip(full[2], pruned[2])), "KV cache differs"
     assert all(torch.equal(a, b) for a, b in zip(full[3], pruned[3])), "generated ids differ"
+
+
+def test_eos_early_exit_in_chunks_of_steps(tiny):
+    """With an eos_id the decode loop is issued 16 steps at a time and stops once every sequence has finished
+    (dualhyp_amd.generate.EOS_CHECK_EVERY).  Against the loop issued in one piece: the same tokens for greedy and for
+    sampled decoding (the per-step RNG counter continues across chunks), rows that finish early stay frozen while the
+    others go on, and the steps actually run are fewer."""
+    import importlib
+    G = importlib.import_module("dualhyp_amd.generate")      # (the package binds the name `generate` to the function)
+    cfg, m, O, o16, o32 = tiny
+    ps = [q.to(DEV) for q in synth_prompts(3, 20, cfg.padded_vocab_size, seed=31)]
+    new = 60
+    free = [o.cpu() for o in generate_batch(m, ps, new, temperature=0.2, top_k=1)]
+    # an EOS that row 0 produces early (its 5th generated token) and the others later or never
+    eos = int(free[0][20 + 4])
+    def cut(o):
+        g = o[20:]
+        hit = (g == eos).nonzero().flatten()
+        return o[: 20 + int(hit[0])] if hit.numel() else o
+    want = [cut(o) for o in free]
+    tm = {}
+    got = [o.cpu() for o in generate_batch(m, ps, new, temperature=0.2, top_k=1, eos_id=eos, timing=tm)]
+    assert all(torch.equal(a, b) for a, b in zip(want, got)), "EOS run differs from the cut free run"
+    # tokens until the last row has produced its EOS (the first token comes from the prompt forward), in whole chunks of 16 steps
+    need = max((int((o[20:] == eos).nonzero().flatten()[0]) + 1) if bool((o[20:] == eos).any()) else new for o in free)
+    expect = new - 1 if need >= new else min(new - 1, max(16, -(-(need - 1) // 16) * 16))
+    assert tm["decode_steps"] == expect, f"{tm['decode_steps']} decode steps run, {expect} expected (all rows done after {need} tokens)"
+    # sampled decoding: chunked == one piece (RNG step counter continuity); eos chosen so that nothing stops early
+    kw = dict(temperature=1.0, top_k=5, seed=77)
+    never = cfg.padded_vocab_size - 1
+    chunked = [o.cpu() for o in generate_batch(m, ps, new, eos_id=never, **kw)]
+    old = G.EOS_CHECK_EVERY
+    try:
+        G.EOS_CHECK_EVERY = 1 << 20
+        whole = [o.cpu() for o in generate_batch(m, ps, new, eos_id=never, **kw)]
+    finally:
+        G.EOS_CHECK_EVERY = old
+    plain = [o.cpu() for o in generate_batch(m, ps, new, **kw)]
+    if all((o[20:] != never).all() for o in plain):
+        assert all(torch.equal(a, b) for a, b in zip(chunked, whole)) and all(torch.equal(a, b) for a, b in zip(chunked, plain))
