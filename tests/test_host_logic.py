@@ -226,3 +226,26 @@ def test_harness_flags_are_the_references():
     assert cfg.name == "tiny-llama-1.1b-chat" and cfg.r == 8 and cfg.alpha == 32 and cfg.to_projection and not cfg.to_mlp
     a.llm_checkpoint = "checkpoints/meta-llama/Llama-3-8B"
     assert inf.config_from_args(a).block_size == 4096          # inference/ger.py:189-190
+
+
+def test_bench_flop_accounting_counts_executed_launches_only():
+    """bench.py's numerator for the prefill-GEMM roofline: with the last block on the last rows (csrc/engine.hip
+    g_prune_last_layer) the last layer contributes its QKV GEMM (+ the q/k/v LoRA side products) alone — neither the rows it
+    skips nor the n_seq-row launches outside the timed class."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from dualhyp_amd import Config, GER_LORA
+    cfg = Config.from_name("tiny-llama-1.1b-chat", **{**GER_LORA, "dropout": 0.0})
+    d, I, L = cfg.n_embd, cfg.intermediate_size, cfg.n_layer
+    qkv = (cfg.n_head + 2 * cfg.n_query_groups) * cfg.head_size
+    n_tok, n_seq = 32 * 512, 32
+    full = bench.gemm_flops_per_prefill(cfg, n_tok, n_seq)
+    assert full == L * n_tok * (2 * d * (qkv + d + 3 * I) + 2 * d * 64 + 2 * 16 * (qkv + d))
+    pruned = bench.gemm_flops_per_prefill(cfg, n_tok, n_seq, last_rows_only=True)
+    last_qkv_only = n_tok * (2 * d * qkv + 2 * d * 48 + 2 * 16 * qkv)
+    assert pruned == (L - 1) * n_tok * (2 * d * (qkv + d + 3 * I) + 2 * d * 64 + 2 * 16 * (qkv + d)) + last_qkv_only
+    merged = bench.gemm_flops_per_prefill(cfg, n_tok, n_seq, merged_lora=True, last_rows_only=True)
+    assert merged == (L - 1) * n_tok * 2 * d * (qkv + d + 3 * I) + n_tok * 2 * d * qkv
