@@ -183,7 +183,7 @@ def result(adapter_path: str, model, tokenizer, args, rank: int = 0, world: int 
     def gen(prompts):
         dev = model.transformer.wte.weight.device
         outs = generate_batch(model, [p.to(dev) for p in prompts], args.max_new_tokens, temperature=0.2, top_k=1, eos_id=eos,
-                              prefill_batch=args.decode_batch)
+                              prefill_batch=max(1, min(args.prefill_batch, args.decode_batch)))
         return [o.cpu() for o in outs]
 
     out = run_inference(gen, examples, tokenizer.decode, batch_size=args.decode_batch, rank=rank, world=world,
@@ -234,7 +234,10 @@ def main(argv: Optional[Sequence[str]] = None) -> Dict[str, Any]:
     p.add_argument("--tokenizer", choices=("auto", "hf", "byte"), default="auto")
     p.add_argument("--config_name", type=str, default=None, help="Config.from_name key (default: the checkpoint directory's name)")
     p.add_argument("--random_init", action="store_true", help="synthetic weights from the counter hash instead of --model_path")
-    p.add_argument("--decode_batch", type=int, default=32, help="utterances per packed prefill / joint decode")
+    p.add_argument("--decode_batch", type=int, default=640,
+                   help="utterances decoded jointly (one weight stream per step for all of them; bench.py: 260 utt/s at 32, 770 at 640); "
+                        "a sequence's tokens do not depend on it")
+    p.add_argument("--prefill_batch", type=int, default=64, help="utterances per packed prefill launch inside a decode batch")
     p.add_argument("--max_new_tokens", type=int, default=150, help="inference/ger.py:71")
     p.add_argument("--predict_dir", type=str, default=None)
     # RelPrompt (inference/relprompt.py): chunk geometry of the reliability masks; with --enc_features_dir (<dir>/<Uid>.pt =
