@@ -324,7 +324,8 @@ def main() -> None:
                        "decode_rows_per_launch": B * min(G, a.steps) if a.schedule == "merged" else B,
                        "prefill_tokens_per_launch": B * PROMPT_LEN * (a.prefill_batches if a.schedule == "merged" else 1),
                        "last_block_rows": "last token of each sequence (proj / MLP of the last block feed only the last-position logits; "
-                                          "K / V of every token are computed)" if pruned else "all",
+                                          "K / V of every token are computed; results bit-equal to the all-rows form, which `--tune 23=0` runs: "
+                                          "759 vs 772 utt/s on one box, DESIGN.md §5)" if pruned else "all",
                        **({"tuning": a.tune} if a.tune else {})},
             "roofline": {"bound": "mfma", "kernel": wl["kernel"],
                          "achieved": achieved, "peak": wl["peak"], "unit": "TFLOP/s",
