@@ -97,6 +97,67 @@ def decode_bytes_per_step(cfg, rows: float, mean_ctx: float, weight_bytes: int, 
     return float(weights + rows * kv * mean_ctx)
 
 
+# HBM-side traffic of the dominant kernel class, per launch, from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled + WRITE_SIZE,
+# MI355X_MICROARCH.md §HBM; separate passes, so it cannot be collected inside the timed run): newest file first
+PMC_TRAFFIC = {
+    "tinyllama-bf16": ["profiles/r04_pmc_gemm.json", "profiles/r03_pmc_gemm_w4.json"],
+    "llama3-8b-fp8": ["profiles/r04_pmc_fp8_gemm256.json", "profiles/r03_pmc_fp8_gemm256.json"],
+}
+
+
+def pmc_traffic(config: str):
+    """(bytes per launch or None, where it came from / why it is null)"""
+    for rel in PMC_TRAFFIC.get(config, []):
+        path = ROOT / rel
+        if not path.exists():
+            continue
+        with open(path) as fh:
+            d = json.load(fh)
+        if "traffic_bytes_per_launch_mean" in d:
+            return d["traffic_bytes_per_launch_mean"], (f"{rel} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_gemm.py, mean bytes per launch "
+                                                          "of the layer's four GEMM launches; L2-miss traffic on the fabric, Infinity-Cache hits included)")
+        if "derived" in d:   # per-kernel fabric bytes (tools/pmc_fp8_summary.py): mean over the kernels of the class
+            v = [k["fabric_read_bytes"] + k["fabric_write_bytes"] for k in d["derived"].values() if "fabric_read_bytes" in k]
+            if v:
+                return sum(v) / len(v), f"{rel} (rocprofv3 --pmc passes over tools/pmc_fp8.py at M = 49152: mean fabric read + write bytes per launch of the profiled kernels)"
+    return None, f"no PMC pass committed for --config {config} (profiles/ holds them for: {', '.join(sorted(PMC_TRAFFIC))})"
+
+
+def _sysfs_clocks(dev_index: int) -> dict:
+    """current sclk / mclk of the card from sysfs (the starred line of pp_dpm_*), best effort: {} when not readable"""
+    out = {}
+    try:
+        p = torch.cuda.get_device_properties(dev_index)
+        bdf = f"{getattr(p, 'pci_domain_id', 0):04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        base = Path("/sys/bus/pci/devices") / bdf
+        for key, fn in (("sclk_mhz", "pp_dpm_sclk"), ("mclk_mhz", "pp_dpm_mclk")):
+            txt = (base / fn).read_text()
+            cur = [l for l in txt.splitlines() if l.strip().endswith("*")]
+            if cur:
+                out[key] = int("".join(c for c in cur[0].split(":")[1] if c.isdigit()))
+        out["pci"] = bdf
+    except Exception:        # noqa: BLE001 - identity is informational
+        pass
+    return out
+
+
+def device_identity(dev_index: int) -> dict:
+    """What the line was measured on (device constants recorded with every run): arch / CU count / HBM bytes from the
+    library's own dh_device_info, name and maximum clocks from the HIP properties, current clocks from sysfs where readable."""
+    import ctypes as C
+    from dualhyp_amd import _lib
+    lib = _lib.load()
+    buf, cu, hbm = C.create_string_buffer(64), C.c_int(0), C.c_int64(0)
+    _lib.check(lib.dh_device_info(buf, 64, C.byref(cu), C.byref(hbm)))
+    p = torch.cuda.get_device_properties(dev_index)
+    d = {"arch": buf.value.decode(), "compute_units": int(cu.value), "hbm_bytes": int(hbm.value), "name": p.name,
+         "max_sclk_mhz": int(getattr(p, "clock_rate", 0) // 1000) or None,
+         "max_mclk_mhz": int(getattr(p, "memory_clock_rate", 0) // 1000) or None,
+         "hip": torch.version.hip, "torch": torch.__version__}
+    d.update({f"{k}_after_run": v for k, v in _sysfs_clocks(dev_index).items()})
+    return d
+
+
 _RESULT_FD = None
 
 
@@ -157,6 +218,10 @@ def main() -> None:
                     help="SURVEY §8d ragged variant: prompt lengths uniform in [384, 640] instead of 512 (not the headline config)")
     ap.add_argument("--pack", type=int, default=32,
                     help="--config finetune-tinyllama: micro-batches of the accumulation window per packed forward/backward launch")
+    ap.add_argument("--repeats", type=int, default=0,
+                    help="timed regions of --steps steps each, run back to back; the line is the MEDIAN one (its own barriers, wall time and "
+                         "HIP-event timings), the others are listed in `repeats`.  Default: 3 when --steps <= 20 (a 0.9-s region moves by +-1.5 %% "
+                         "from run to run and box to box), else 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap-probe", action="store_true")
     ap.add_argument("--tune", action="append", default=[], metavar="KEY=VALUE",
@@ -274,31 +339,42 @@ def main() -> None:
         flat = lambda bs: [p for b in bs for p in b]
         pipe.warm(flat([batches[0]] * min(G, a.steps)), NEW_TOKENS, prefill_batch=B, **gen_kw)
         engs = [m.engine() for m in pipe.models]
-    for e in engs:
-        e.set_timing(True)
-    phase.clear()
-    barrier()
-    t0 = time.perf_counter()
-    if a.schedule == "merged":
-        outs = run_merged(batches[n_warm:])
-    else:
-        timed = batches[n_warm:]
-        futs = [pipe.submit(flat(timed[g:g + G]), NEW_TOKENS, prefill_batch=B, **gen_kw) for g in range(0, len(timed), G)]
-        outs = [o[i:i + B] for f in futs for o in [f.result()] for i in range(0, len(o), B)]
-    barrier()
-    dt = time.perf_counter() - t0
-    gemm_ms = gemm_n = attn_ms = 0
-    for e in engs:
-        ms, n = e.get_timing(0)
-        gemm_ms, gemm_n = gemm_ms + ms, gemm_n + n
-        attn_ms += e.get_timing(2)[0]
-        e.set_timing(False)
     timed_prompts = [p for b in batches[n_warm:] for p in b]
-    assert all(o.numel() == p.numel() + NEW_TOKENS for o, p in zip([o for out in outs for o in out], timed_prompts))
-    if use_pg:
-        tt = torch.tensor([dt], device="cpu" if rehearsal else dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    n_rep = a.repeats if a.repeats > 0 else (3 if a.steps <= 20 else 1)
+    runs = []
+    for _rep in range(n_rep):
+        # one timed region: EXACTLY --steps steps between barrier + synchronize on both sides, MAX over ranks
+        for e in engs:
+            e.set_timing(True)          # (re)starts the HIP-event record of the kernel classes
+        phase.clear()
+        barrier()
+        t0 = time.perf_counter()
+        if a.schedule == "merged":
+            outs = run_merged(batches[n_warm:])
+        else:
+            timed = batches[n_warm:]
+            futs = [pipe.submit(flat(timed[g:g + G]), NEW_TOKENS, prefill_batch=B, **gen_kw) for g in range(0, len(timed), G)]
+            outs = [o[i:i + B] for f in futs for o in [f.result()] for i in range(0, len(o), B)]
+        barrier()
+        dt = time.perf_counter() - t0
+        gemm_ms = gemm_n = attn_ms = 0
+        for e in engs:
+            ms, n = e.get_timing(0)
+            gemm_ms, gemm_n = gemm_ms + ms, gemm_n + n
+            attn_ms += e.get_timing(2)[0]
+            e.set_timing(False)
+        assert all(o.numel() == p.numel() + NEW_TOKENS for o, p in zip([o for out in outs for o in out], timed_prompts))
+        if use_pg:
+            tt = torch.tensor([dt], device="cpu" if rehearsal else dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        runs.append(dict(dt=dt, gemm_ms=gemm_ms, gemm_n=gemm_n, attn_ms=attn_ms, phase=dict(phase), outs=outs))
+    # the line describes the MEDIAN region (by wall time, the same one on every rank: dt is already the max over ranks)
+    order = sorted(range(n_rep), key=lambda i: runs[i]["dt"])
+    med = runs[order[(n_rep - 1) // 2]]
+    dt, gemm_ms, gemm_n, attn_ms, outs = med["dt"], med["gemm_ms"], med["gemm_n"], med["attn_ms"], med["outs"]
+    phase.clear()
+    phase.update(med["phase"])
 
     result = None
     if rank == 0:
@@ -307,16 +383,16 @@ def main() -> None:
         flops = gemm_flops_per_prefill(cfg, sum(p.numel() for p in timed_prompts), B * a.steps, merged_lora=wl["fp8"],
                                        last_rows_only=pruned)
         achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        traffic = None   # HBM-side bytes per launch from the committed PMC passes
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_gemm_w4.json")
-        if os.path.exists(pmc) and a.config == "tinyllama-bf16":
-            with open(pmc) as fh:
-                traffic = json.load(fh).get("traffic_bytes_per_launch_mean")
+        traffic, traffic_source = pmc_traffic(a.config)   # HBM-side bytes per launch from the committed PMC passes
         result = {
             "metric": wl["metric"],
             "value": utt / dt, "unit": "utterances/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": wl["dtype"], "data": "synthetic",
+            "repeats": {"timed_regions": n_rep, "reported": "median by wall time", "ms_per_step_all": [r["dt"] / a.steps * 1e3 for r in runs],
+                        "value_all": [utt / r["dt"] for r in runs],
+                        "spread_pct": (max(r["dt"] for r in runs) - min(r["dt"] for r in runs)) / dt * 100.0},
+            "device": device_identity(local),
             "config": {"workload": wl["what"],
                        "batch_per_gpu": B, "prompt_tokens": f"uniform {PROMPT_LEN * 3 // 4}..{PROMPT_LEN * 5 // 4}" if a.ragged else PROMPT_LEN,
                        "new_tokens": NEW_TOKENS,
@@ -330,9 +406,7 @@ def main() -> None:
             "roofline": {"bound": "mfma", "kernel": wl["kernel"],
                          "achieved": achieved, "peak": wl["peak"], "unit": "TFLOP/s",
                          "frac": achieved / wl["peak"], "traffic": traffic,
-                         "traffic_source": ("profiles/r03_pmc_gemm_w4.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/pmc_gemm.py, mean bytes per "
-                                            "launch; L2-miss traffic on the fabric, Infinity-Cache hits included)") if traffic is not None else
-                                           "not collected for this workload (PMC passes exist for the headline config's GEMMs only)",
+                         "traffic_source": traffic_source,
                          "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
                          "prefill_attention_ms_per_step": attn_ms / max(a.steps, 1)},
         }
@@ -484,7 +558,7 @@ def bench_finetune(a, wl, cfg, model, dev, rank: int, world: int, rehearsal: boo
         emit({
             "metric": wl["metric"], "value": utt / dt, "unit": "utterances/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": wl["dtype"],
-            "data": "synthetic",
+            "data": "synthetic", "device": device_identity(dev.index),
             "config": {"workload": wl["what"], "global_batch": GLOBAL, "micro_batches_per_rank_per_step": per_rank, "tokens": T,
                        "micro_batches_per_packed_launch": PACK,
                        "parallelism": f"data-parallel x{world}, flat LoRA-gradient bucket of {bucket.flat.numel()} fp32 elements",
@@ -509,6 +583,7 @@ def _cpu_model() -> str:
     return platform.processor() or "unknown"
 
 
+CLOSENESS_GATE = 1.25   # relRMS(hip, oracle bf16) / relRMS(oracle bf16, fp32) allowed on the pooled last-position logits (measured 1.08)
 N_PARITY = 4      # utterances of the timed region the oracle's ids / prefill logits are compared on
 
 
@@ -622,8 +697,11 @@ def parity_vs_oracle(model, prompts, hip_ids_timed, refs, gen_kw) -> dict:
     # relRMS(HIP, oracle bf16) <= sqrt(2) x relRMS(oracle bf16, f).  (A ratio below 1 needs the two runs' rounding errors
     # to be correlated by more than 0.5 — true of the tests' short fixtures, where HIP reproduces the CPU kernels'
     # rounding points bit for bit; at T = 512 over 22 layers the online-softmax tiling of the two attention kernels
-    # differs and the measured ratio is 0.93..1.18 by prompt.  Both numbers are on the line.)
-    logits_ok = acc <= 1.05 * yard and e_hip <= 1.5 * e_ref and rr <= 2 ** 0.5 * yard
+    # differs and the measured ratio is 0.93..1.18 by prompt, 1.08 pooled over the four.  The gate is CLOSENESS_GATE = 1.25 on the pooled
+    # figure — set from that measurement (sqrt(2) allowed fully independent errors and hid that the HIP logits sit
+    # further from the reference's bf16 run than that run sits from fp32); the tests' 1.0 x gate is the teacher-forced one
+    # (tests/test_hip_model.py::gate).  Both numbers and their ratio are on the line.)
+    logits_ok = acc <= 1.05 * yard and e_hip <= 1.5 * e_ref and rr <= CLOSENESS_GATE * yard
     out = {"utterances": f"first {len(refs)} utterances of the timed region", "generated_tokens": G,
            "ids_equal_prefix_timed_run": [r["ids_equal_prefix_timed_run"] for r in per],
            "oracle_tie_free_prefix": [r["oracle_tie_free_prefix"] for r in per],
@@ -633,7 +711,8 @@ def parity_vs_oracle(model, prompts, hip_ids_timed, refs, gen_kw) -> dict:
            "rel_rms_hip_vs_oracle_bf16_over_yardstick": rr / yard,
            "prefill_last_logits_max_abs_vs_fp32": e_hip, "oracle_bf16_max_abs_vs_fp32": e_ref,
            "logits_gate": "relRMS(hip, fp32) <= 1.05 x relRMS(oracle bf16, fp32) and max|hip - fp32| <= 1.5 x max|oracle bf16 - fp32| and "
-                          "relRMS(hip, oracle bf16) <= sqrt(2) x relRMS(oracle bf16, fp32), last-position prefill logits of the utterances pooled",
+                          f"relRMS(hip, oracle bf16) <= {CLOSENESS_GATE} x relRMS(oracle bf16, fp32), last-position prefill logits of the utterances pooled "
+                          "(free-running prompts of the timed region; the tests' 1.0 x gate is the teacher-forced one on the reference's own fixtures)",
            "ids_pass": bool(ok_ids), "logits_pass": bool(logits_ok), "per_utterance": per}
     out["pass"] = bool(out["ids_pass"] and out["logits_pass"])
     return out

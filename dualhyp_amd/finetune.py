@@ -125,21 +125,55 @@ def micro_loss(model, input_ids: torch.Tensor, labels: torch.Tensor, chunk: int)
     return chunked_cross_entropy(logits, labels[..., 1:], chunk_size=chunk)
 
 
+def _all_reduce_sum(t: torch.Tensor) -> torch.Tensor:
+    """SUM over the ranks of a small tensor (validation totals, flags): RCCL on device tensors, staged through the host under the
+    one-GPU gloo rehearsal; the identity without a process group."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return t
+    if dist.get_backend() == "gloo" and t.is_cuda:
+        host = t.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        return host.to(t.device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def _barrier() -> None:
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
 @torch.no_grad()
-def validate(model, batches: Iterable[Dict[str, torch.Tensor]]) -> float:
-    """finetune/ger.py:331-353: mean over batches of the CE on valid positions; all-masked batches skipped."""
+def validate(model, batches: Iterable[Dict[str, torch.Tensor]], rank: int = 0, world: int = 1) -> float:
+    """finetune/ger.py:331-353: mean over batches of the CE on valid positions; all-masked batches skipped.
+
+    Data-parallel form (the reference runs the WHOLE set on every rank and synchronises once per batch through `.item()`):
+    rank r takes batches r, r + world, ... of the iterable (host tensors are moved to the model's device only for those),
+    accumulates (loss sum, batch count) on the device, and ONE all-reduce of the two numbers + ONE host read end the
+    validation — every rank returns the same global mean, so the `best_val` decision is identical everywhere."""
     was_training = model.training
     model.eval()
-    losses = []
-    for b in batches:
+    dev = next(model.parameters()).device
+    tot = torch.zeros(2, dtype=torch.float64, device=dev)            # [sum of per-batch losses, batches counted]
+    for i, b in enumerate(batches):
+        if i % world != rank:
+            continue
         ids, tg = b["input_ids"], b["labels"]
+        # the skip test of finetune/ger.py:341-344 on the HOST copy of the labels when there is one (no device sync)
         if int((tg[..., 1:] != -1).sum()) == 0:
             continue
+        ids, tg = ids.to(dev), tg.to(dev)
         lg = model(ids)
-        losses.append(chunked_cross_entropy(lg[..., :-1, :], tg[..., 1:], chunk_size=0).item())
+        tot[0] += chunked_cross_entropy(lg[..., :-1, :], tg[..., 1:], chunk_size=0).double()
+        tot[1] += 1
     model.reset_cache()
     model.train(was_training)
-    return sum(losses) / max(len(losses), 1)
+    if world > 1:
+        tot = _all_reduce_sum(tot)
+    s, n = tot.tolist()                                              # the validation's one host synchronisation
+    return s / max(n, 1.0)
 
 
 from .checkpoint import save_checkpoint  # noqa: E402,F401  (finetune/ger.py:356-358)
@@ -180,6 +214,23 @@ def fit(model, train_examples: Sequence[Dict[str, torch.Tensor]], collate: Calla
         from .train import GraphedTrainStep
         packed = GraphedTrainStep(model, bucket)
     pending: List[tuple] = []                           # (iteration, example) of micro-batches not yet run (pack > 1)
+    saves = 0
+
+    def checkpoint_if_best(tag: str) -> None:
+        """finetune/ger.py:309-317: validate, save `best_model.pth` when the validation loss improved, barrier.  The loss is the
+        global mean (validate all-reduces), so every rank takes the same branch; rank 0 alone writes (the LoRA tensors are
+        replicated: every rank holds the same ones after the all-reduced optimizer step) and the others wait at the barrier, so
+        the next optimizer step cannot start under the save."""
+        nonlocal best_val, saves
+        v = validate(model, val_batches(), rank, world)
+        log(f"{tag} val loss {v:.4f}")
+        if v < best_val:
+            best_val = v
+            if out_dir and rank == 0:
+                save_checkpoint(model, Path(out_dir) / "best_model.pth")
+                saves += 1
+        if world > 1:
+            _barrier()
 
     def flush() -> None:
         """run the pending micro-batches as one packed step; per-micro-batch bookkeeping as if they had run in turn"""
@@ -235,22 +286,15 @@ def fit(model, train_examples: Sequence[Dict[str, torch.Tensor]], collate: Calla
                 last = (loss_acc / cfg.save_interval).item()
                 loss_acc.zero_()
                 if val_batches is not None:
-                    v = validate(model, val_batches())
-                    log(f"iter {it}: train loss {last:.4f} val loss {v:.4f}")
-                    if v < best_val:
-                        best_val = v
-                        if out_dir and rank == 0:
-                            save_checkpoint(model, Path(out_dir) / "best_model.pth")
+                    checkpoint_if_best(f"iter {it}: train loss {last:.4f}")
     flush()     # micro-batches after the last optimizer step of the run (their gradients are dropped, as in the reference's loop)
     if val_batches is not None:
-        v = validate(model, val_batches())
-        if v < best_val:
-            best_val = v
-            if out_dir and rank == 0:
-                save_checkpoint(model, Path(out_dir) / "best_model.pth")
+        checkpoint_if_best(f"iter {it} (end)")
     if out_dir and rank == 0:
         save_checkpoint(model, Path(out_dir) / "lit_model_lora_finetuned.pth")
-    return {"final_train_loss": last, "best_val_loss": best_val, "optimizer_steps": steps}
+    if world > 1:
+        _barrier()                          # nobody leaves (and tears the group down) while rank 0 still writes
+    return {"final_train_loss": last, "best_val_loss": best_val, "optimizer_steps": steps, "checkpoints_written": saves}
 
 
 # ------------------------------------------------------------------------------------------ harness
@@ -370,12 +414,12 @@ def main(argv: Optional[Sequence[str]] = None) -> Dict[str, float]:
     val_batches = None
     if args.val_path:
         val_ds = dataset(args.val_path, args.seed)
-        val = [val_ds[i] for i in range(len(val_ds))][rank::world]
+        val = [val_ds[i] for i in range(len(val_ds))]
 
-        def val_batches():
+        def val_batches():                 # host tensors of the WHOLE set: validate() takes this rank's share and moves only that
             for b in range(0, len(val), args.micro_batch_size):
                 c = collate(val[b:b + args.micro_batch_size])
-                yield {"input_ids": c["input_ids"].to(dev), "labels": c["labels"].to(dev)}
+                yield {"input_ids": c["input_ids"], "labels": c["labels"]}
     tc = TrainConfig(learning_rate=args.lr, weight_decay=args.weight_decay, num_epochs=args.num_epochs, batch_size=args.batch_size,
                      micro_batch_size=args.micro_batch_size, warmup_frac=args.wp, use_cosine_scheduler=args.use_cosine_scheduler,
                      min_lr_ratio=args.min_lr_ratio, save_interval=max(args.save_interval // world, 1),
@@ -391,8 +435,7 @@ def main(argv: Optional[Sequence[str]] = None) -> Dict[str, float]:
         logging.info(f"result: {out}")
     if world > 1:
         import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
+        dist.destroy_process_group()        # fit() ended on a barrier behind rank 0's last checkpoint
     return out
 
 

@@ -304,12 +304,21 @@ class GraphedTrainStep:
     Sequences are right-padded to a common multiple of `pad_to` with ignored positions: causal attention and the
     row-wise kernels make real positions independent of the padding, ignored rows get zero gradient."""
 
-    def __init__(self, model: GPT, bucket, pad_to: int = 64) -> None:
+    def __init__(self, model: GPT, bucket, pad_to: int = 64, max_graphs: int = 8) -> None:
         self.model, self.bucket, self.pad_to = model, bucket, pad_to
         self.params = lora_parameters(model)
         n = len(self.params)
         assert [id(p) for p in self.params] == [id(p) for p in bucket.params[:n]], "bucket must start with lora_parameters(model) in order"
-        self._graphs = {}
+        # Graph cache (ADVICE r03, medium).  A captured micro-step holds every saved activation of its P x T_pad rows (~1.3 MB per row
+        # on TinyLlama: ~6 GB for 8 x 576); ragged data produce tens of (T_pad, n_rows) keys.  So: (1) ALL graphs capture into ONE
+        # memory pool — they never replay concurrently and nothing allocated inside `_body` outlives it, so the pool is as large as
+        # the largest graph, not their sum; (2) the cache is an LRU of at most `max_graphs` entries (an evicted key is captured
+        # again when it comes back: ~1 s); (3) the head's row count is rounded to 256 so fewer keys exist.
+        import collections
+        self._graphs = collections.OrderedDict()
+        self.max_graphs = max(1, int(max_graphs))
+        self._pool = None
+        self.captures = 0
 
     def _body(self, st) -> None:
         model, V = self.model, self.model.config.padded_vocab_size
@@ -373,12 +382,18 @@ class GraphedTrainStep:
             lens_h = torch.tensor(lengths, device=labels.device).view(-1, 1)
             colh = torch.arange(1, W, device=labels.device).view(1, -1)
             n_targets = int(((labels[:, 1:W] != -1) & (colh < lens_h)).sum())
-        n_rows = min(P * T_pad, max(128, -(-int(n_targets) // 128) * 128))
+        n_rows = min(P * T_pad, max(128, -(-int(n_targets) // 256) * 256))
         gkey = (P, T_pad, Vw, n_rows)        # the rsqrt-emulation switch is resolved while capturing: part of the key
         ent = self._graphs.get(gkey)
         if ent is None:
+            while len(self._graphs) >= self.max_graphs:          # least recently used first; its blocks go back to the shared pool
+                _, old = self._graphs.popitem(last=False)
+                old[1] = None
+                old[0].clear()
             st = self._state(P, T_pad, dev, n_rows)
             ent = self._graphs[gkey] = [st, None]
+        else:
+            self._graphs.move_to_end(gkey)
         st = ent[0]
         st["ids"].zero_()
         st["ids"][:, :W].copy_(input_ids[:, :W])
@@ -399,6 +414,13 @@ class GraphedTrainStep:
             # Q11: a micro-batch-1 call of the reference has T_i rows; its rows past the last whole vector take the scalar loop
             st["tail"].view(P, T_pad).copy_(((col >= (lens_d // Vw * Vw).view(-1, 1)) & (col < lens_d.view(-1, 1))).to(torch.uint8))
         if ent[1] is None:
+            # A caller-supplied n_targets is trusted on replays (counting on the device would be a host sync per step); it is
+            # CHECKED once per graph key, here, where a capture costs a second anyway: an undercount would silently drop target
+            # rows from the loss and the gradient.
+            have = int((st["targets"] >= 0).sum())
+            if have > n_rows:
+                del self._graphs[gkey]
+                raise ValueError(f"GraphedTrainStep: n_targets={n_targets} but the labels carry {have} targets (> {n_rows} head rows)")
             # warm-up outside capture (allocations, lazy initialisation), with its gradient contribution undone
             keep = self.bucket.flat.clone()
             side = torch.cuda.Stream(device=dev)
@@ -408,8 +430,11 @@ class GraphedTrainStep:
             torch.cuda.current_stream(dev).wait_stream(side)
             self.bucket.flat.copy_(keep)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            if self._pool is None:
+                self._pool = torch.cuda.graph_pool_handle()
+            with torch.cuda.graph(g, pool=self._pool):
                 self._body(st)
+            self.captures += 1
             self.bucket.flat.copy_(keep)          # capture does not execute, but keep the invariant explicit
             ent[1] = g
         ent[1].replay()

@@ -469,7 +469,7 @@ def gen_relprompt(rgenerate_unused, name: str, cfg_name: str, r: int, seed: int)
 
 
 
-def gen_relprompt_full(name: str, seed: int, T: int, G: int) -> None:
+def gen_relprompt_full(name: str, seed: int, T: int, G: int, decided_prefix: int = 0, max_tries: int = 64) -> None:
     """BASELINE config 4 at FULL size (VERDICT r02 missing #7): ger.relprompt.GPT with TinyLlama-1.1B's 22 layers and the
     GER LoRA set, plain N(0, 0.02) hash weights with nothing tied, wte grown by resize_token_embeddings(3), a T-token prompt
     carrying one reliability token per 0.4 s chunk of both streams (two runs of 28 ids in V..V+2), G tokens by the greedy
@@ -483,11 +483,15 @@ def gen_relprompt_full(name: str, seed: int, T: int, G: int) -> None:
     cfg = Config.from_name("tiny-llama-1.1b-chat", **{**GER_LORA, "dropout": 0.0})
     V, d = cfg.padded_vocab_size, cfg.n_embd
     extra = uniform((3, d), 0.02 * math.sqrt(3.0), stream_id(seed, "transformer.wte.reliability_rows"))
-    idx = synth_prompts(1, T, V, seed=seed)[0]
     marks = (uniform((56,), 1.5, stream_id(seed, "reliability_marks"), dtype=torch.float32) + 1.5).floor().clamp(0, 2).long() + V
-    idx[40:68], idx[300:328] = marks[:28], marks[28:]
+
+    def prompt(pseed):
+        idx = synth_prompts(1, T, V, seed=pseed)[0]
+        idx[40:68], idx[300:328] = marks[:28], marks[28:]
+        return idx
+    idx, prompt_seed = prompt(seed), seed
     kw = cfg_kwargs_of(cfg, relprompt=True)
-    out = {"idx": idx, "wte_extra_rows": extra}
+    out = {"wte_extra_rows": extra}
 
     def build(dt):
         sd = synth_state_dict(cfg, seed=seed)
@@ -508,6 +512,29 @@ def gen_relprompt_full(name: str, seed: int, T: int, G: int) -> None:
 
     m = build(torch.bfloat16)
     fwd = lambda x, pos: m(x, input_pos=pos)
+    if decided_prefix:
+        # with i.i.d. random logits the reference's own arg-max is a near-tie on a quarter of the steps, and
+        # seed 1337's prompt has one at step 0 (an empty tie-free prefix).  Same weights, other PROMPTS (synth_prompts seeds
+        # seed + 1, ...): keep the first whose first `decided_prefix` greedy steps the reference decides by >= 4 bf16 ulps.
+        for t_ in range(1, max_tries + 1):
+            cand = prompt(seed + t_)
+            with torch.no_grad():
+                lg = m(cand.view(1, -1), input_pos=torch.arange(T))[0, -1]
+                ok = 0
+                for s_ in range(decided_prefix):
+                    if top2_margin_ulps(lg) < 4:
+                        break
+                    ok += 1
+                    nx = lg.float().argmax().view(1, 1)
+                    lg = m(nx, input_pos=torch.tensor([T + s_]))[0, 0]
+                m.reset_cache()
+            print(f"prompt seed {seed + t_}: {ok} decided steps", flush=True)
+            if ok == decided_prefix:
+                idx, prompt_seed = cand, seed + t_
+                break
+        else:
+            raise SystemExit("no prompt with a decided prefix found")
+    out["idx"] = idx
     with torch.no_grad():
         torch.manual_seed(seed)
         pos = torch.arange(T)
@@ -529,7 +556,7 @@ def gen_relprompt_full(name: str, seed: int, T: int, G: int) -> None:
     _, f32, tv32, ti32 = _margins_teacher_forced(m, idx, g, T, G, fwd=lambda x, pos: m(x, input_pos=pos))
     out["step_logits_fp32_v4096"] = f32
     out["step_top8_values_fp32"], out["step_top8_indices_fp32"] = tv32, ti32
-    save(name, out, {"config": kw, "seed": seed, "T": T, "G": G, "reliability_tokens": 56,
+    save(name, out, {"config": kw, "seed": seed, "prompt_seed": prompt_seed, "T": T, "G": G, "reliability_tokens": 56,
                      "generate_loop": "restated over ger.relprompt.GPT.forward"})
 
 def _train_micro(rlora, rutils, m, ids, labels, chunk, accum, autocast):
@@ -794,7 +821,7 @@ def main() -> None:
         gen_relprompt(rgenerate, "relprompt_tiny", "parity-tiny", r=4, seed=2024)
         gen_relprompt(rgenerate, "relprompt_hs128", "parity-hs128", r=16, seed=2025)
     if want("relprompt_full") and not a.skip_full:   # VERDICT r02 missing #7: config 4's decoder at full size
-        gen_relprompt_full("relprompt_tinyllama", seed=1337, T=560, G=16)
+        gen_relprompt_full("relprompt_tinyllama", seed=1337, T=560, G=16, decided_prefix=8)
     if want("adamw"):
         gen_adamw(rlora, rutils, "adamw_tiny", "parity-tiny", r=4, seed=99)
     if want("train_shape") and not a.skip_full:
@@ -803,6 +830,8 @@ def main() -> None:
         gen_train_shape(rlora, rutils, "train_tinyllama_full", seed=1337, T=560, n_layer=22, keep_layers={0, 21})
     if want("llama3") and not a.skip_full:
         gen_llama3_shape(rlora, rgenerate, "llama3_shape", seed=1337, T=96, G=12, n_layer=2)
+    if want("llama3_1536") and not a.skip_full:   # config 5 at its real prompt length (24 key tiles of 64, 12 pair-sum splits)
+        gen_llama3_shape(rlora, rgenerate, "llama3_shape_1536", seed=1337, T=1536, G=16, n_layer=2)
     if a.only == "full512" or (not a.only and not a.skip_full):
         gen_full512(rlora, rgenerate, "full_tinyllama_512", seed=1337, T=512, G=64)
     if want("full512_untied") and not a.skip_full:

@@ -31,3 +31,10 @@ def test_bench_line_has_the_contract_fields():
     assert 0.05 < r["frac"] < 1.0 and d["value"] > 50
     assert d["roofline_decode"]["bound"] == "hbm" and 32 <= d["phases"]["decode_rows_per_launch"] <= 64   # groups of 2 and 1 batches
     assert d["config"]["prefill_tokens_per_launch"] == 2 * 32 * 512
+    # round 4: the line says what it was measured on and how far its repeats were apart
+    dev = d["device"]
+    assert dev["arch"].startswith("gfx950") and dev["compute_units"] == 256 and dev["hbm_bytes"] > 200e9 and dev["name"]
+    rep = d["repeats"]
+    assert rep["timed_regions"] == 3 and len(rep["ms_per_step_all"]) == 3 and rep["reported"] == "median by wall time"
+    assert sorted(rep["ms_per_step_all"])[1] == pytest.approx(d["ms_per_step"]) and rep["spread_pct"] >= 0
+    assert r["traffic"] is not None and "profiles/" in r["traffic_source"]

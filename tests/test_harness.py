@@ -27,10 +27,10 @@ def _env(**extra):
     return env
 
 
-def merged_items(n=7):
+def merged_items(n=7, caps=None):
     """Items with every key of the merged schema (data/merge_json.py:5-63; README.md:78-89)."""
-    caps = ["the cat sat on the mat", "we went home early", "it is raining again", "open the window please", "she sells sea shells",
-            "nothing to see here", "turn left at the light"]
+    caps = caps or ["the cat sat on the mat", "we went home early", "it is raining again", "open the window please", "she sells sea shells",
+                    "nothing to see here", "turn left at the light"]
     items = []
     for i in range(n):
         c = caps[i % len(caps)]
@@ -49,45 +49,82 @@ def merged_items(n=7):
 
 
 NEW = 10
+# The harness fixture's decoder SAYS something (random weights gave WER 1.0 == 1.0 on both sides, an equality
+# that proves nothing).  dualhyp_amd.synth ties the head to the embedding through a successor permutation; here the permutation
+# is chosen so that the cycle through "\n" — the last token of every prompt, "### Response:\n" — spells SAYS: every utterance is
+# answered "up down", and the captions are picked so the corpus WER is a known fraction strictly between 0 and 1.
+SAYS = "up down"
+CAPTIONS = ["up down", "up town", "sit down", "up down now", "up", "we went up down there", "down up"]
+# word errors against "up down": 0 + 1 (sub) + 1 (sub) + 1 (del) + 1 (ins) + 3 (del) + 2 = 9 over 2 + 2 + 2 + 3 + 1 + 5 + 2 = 17 reference words
+WANT_WER, WANT_EXACT = 9 / 17, 1
 
 
-def test_inference_harness_end_to_end(tmp_path):
+def speaking_state_dict(cfg, seed):
+    """synth_state_dict(weight_scale 4, embed_scale 64) with the head tied through a permutation whose cycle through the
+    byte-tokenizer's "\n" reads SAYS: lm_head[v] = random[v] + wte_unscaled[pred(v)], pred(first) = "\n", pred(next) = previous, ...,
+    pred("\n") = last; every other token keeps a successor too (one more cycle), so the map stays a permutation."""
+    import math
+    from dualhyp_amd.synth import synth_state_dict, uniform, stream_id
+    sd = synth_state_dict(cfg, seed=seed, weight_scale=4.0, embed_scale=64.0, head_tie=0.0)
+    V, d = cfg.padded_vocab_size, cfg.n_embd
+    cyc = [ord("\n") + 3] + [b + 3 for b in SAYS.encode()]
+    assert len(set(cyc)) == len(cyc), "a permutation cycle visits a token once: SAYS must not repeat a character"
+    rest = [v for v in range(V) if v not in cyc]
+    pred = torch.empty(V, dtype=torch.int64)
+    for chain in (cyc, rest):
+        for i, v in enumerate(chain):
+            pred[v] = chain[i - 1]
+    a = 0.02 * math.sqrt(3.0) * 4.0
+    raw = uniform((V, d), a, stream_id(seed, "transformer.wte.weight"), "cpu", torch.float32)     # the embedding before embed_scale
+    sd["lm_head.linear.weight"] = (sd["lm_head.linear.weight"].float() + raw[pred]).to(torch.bfloat16)
+    return sd
+
+
+@pytest.mark.parametrize("fmt", ["DualHyp", "GER"])
+def test_inference_harness_end_to_end(tmp_path, fmt):
+    """`python -m dualhyp_amd.inference` on a merged-schema JSON, in the DualHyp format (data/av_dataset.py:373-429) and in the
+    ASR-only GER format of BASELINE configs[0] (data/av_dataset.py:210-256, data/prompts.py:3-7; VERDICT r03 missing #6), against
+    `run_inference` fed the ORACLE's ids for the same prompts — with a decoder whose corpus WER is a known value in (0, 1)."""
     from dualhyp_amd import Config
     from dualhyp_amd.data import HypothesesDataset
     from dualhyp_amd.inference import run_inference
-    from dualhyp_amd.synth import synth_state_dict
     from dualhyp_amd.tokenizer import ByteTokenizer
     from dualhyp_amd.wer import wer_counts, post_normalize
     from oracle import ger_oracle as O
+    items = merged_items(caps=CAPTIONS)
     test_json = tmp_path / "test.json"
-    test_json.write_text(json.dumps(merged_items()))
+    test_json.write_text(json.dumps(items))
     ckpt_dir = tmp_path / "checkpoints" / "parity-harness"
     ckpt_dir.mkdir(parents=True)
     lora = dict(r=16, alpha=16, dropout=0.05, to_query=True, to_key=True, to_value=True, to_projection=True)
     cfg = Config.from_name("parity-harness", **lora)
-    sd = synth_state_dict(cfg, seed=31, weight_scale=4.0, embed_scale=64.0, head_tie=1.0)   # robust arg-max margins (synth.py)
+    sd = speaking_state_dict(cfg, seed=31)
     run_dir = tmp_path / "runs" / "exp"
     run_dir.mkdir(parents=True)
     torch.save({"model": sd}, run_dir / "best_model.pth")                      # finetune/ger.py:356-358 format
     cmd = [sys.executable, "-m", "dualhyp_amd.inference", "--test_path", str(test_json), "--model_path", str(run_dir / "best_model.pth"),
-           "--llm_checkpoint", str(ckpt_dir), "--dual_hypotheses", "--prompts_format", "DualHyp", "--tokenizer", "byte",
-           "--max_new_tokens", str(NEW), "--decode_batch", "4"]
+           "--llm_checkpoint", str(ckpt_dir), "--prompts_format", fmt, "--tokenizer", "byte",
+           "--max_new_tokens", str(NEW), "--decode_batch", "4"] + (["--dual_hypotheses"] if fmt == "DualHyp" else [])
     out = subprocess.run(cmd, cwd=tmp_path, env=_env(), capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     pred_file = run_dir / "predictions" / "best_model.json"                    # inference/ger.py:120-122
     js = json.loads(pred_file.read_text())
     assert len(js) == 7 + 2 and set(js[0]) == {"inference", "ground_truth"} and set(js[-2]) == {"wer", "gtms"} and set(js[-1]) == {"post_wer", "post_gtms"}
     preds = js[:7]
-    assert [p["ground_truth"] for p in preds] == [it["Caption"] for it in merged_items()]
+    assert [p["ground_truth"] for p in preds] == [it["Caption"] for it in items]
     c = wer_counts([p["inference"] for p in preds], [p["ground_truth"] for p in preds])
     assert js[-2]["wer"] == pytest.approx(c["errors"] / c["ref_words"]) and js[-2]["gtms"] == f"{c['exact']}/7"
     cp = wer_counts([post_normalize(p["inference"]) for p in preds], [post_normalize(p["ground_truth"]) for p in preds])
     assert js[-1]["post_wer"] == pytest.approx(cp["errors"] / cp["ref_words"])
     # ---- the same pipeline with the ORACLE as the decoder (CPU, batch 1 as the reference): ids and margins per utterance
     tok = ByteTokenizer()
-    ds = HypothesesDataset(str(test_json), tok, prompts_format="DualHyp", seed=1337)
+    ds = HypothesesDataset(str(test_json), tok, prompts_format=fmt, seed=1337)
     exs = [ds[i] for i in range(len(ds))]
-    assert all(e["input_no_response"].endswith("### Response:\n") and "### VSR Other-hypotheses:\n" in e["input_no_response"] for e in exs)
+    assert all(e["input_no_response"].endswith("### Response:\n") for e in exs)
+    if fmt == "DualHyp":
+        assert all("### VSR Other-hypotheses:\n" in e["input_no_response"] for e in exs)
+    else:       # the ASR-only prompt: best hypothesis + the other ASR hypotheses, nothing of the VSR stream (data/prompts.py:3-7)
+        assert all("VSR" not in e["input_no_response"] and it["nhyps_asr"]["hyps"][4] in e["input_no_response"] for e, it in zip(exs, items))
     om = O.OracleGPT(cfg, sd)
     safe_all, table = [], {}
     for e in exs:
@@ -101,14 +138,19 @@ def test_inference_harness_end_to_end(tmp_path):
     ref = run_inference(lambda ps: [table[tuple(p.tolist())] for p in ps], exs, tok.decode, batch_size=4)
     n_safe = sum(safe_all)
     from conftest import record_parity
-    record_parity("harness.inference_vs_oracle", utterances=7, utterances_all_steps_margin_ge4=n_safe,
+    record_parity(f"harness.inference_vs_oracle.{fmt}", utterances=7, utterances_all_steps_margin_ge4=n_safe,
                   predictions_equal=sum(a["inference"] == b["inference"] for a, b in zip(preds, ref["predictions"])),
-                  wer_hip=js[-2]["wer"], wer_oracle=ref["WER"])
+                  predictions_as_designed=sum(p["inference"] == SAYS for p in preds),
+                  wer_hip=js[-2]["wer"], wer_oracle=ref["WER"], wer_by_hand=WANT_WER)
     assert n_safe >= 3, "fixture too tie-prone to say anything"
     for i, ok in enumerate(safe_all):
         if ok:
             assert preds[i]["inference"] == ref["predictions"][i]["inference"], f"utterance {i}: HIP harness and oracle disagree on a tie-free decode"
-    if n_safe == 7:
+    # the oracle's decoder says what the permutation was built to say, so the corpus WER is the hand-computed 9 / 17 ...
+    assert [p["inference"] for p in ref["predictions"]] == [SAYS] * 7 and ref["WER"] == pytest.approx(WANT_WER)
+    assert 0.0 < ref["WER"] < 1.0
+    if n_safe == 7:   # ... and so is the HIP harness's, word errors and exact matches alike
+        assert js[-2]["wer"] == pytest.approx(WANT_WER) and js[-2]["gtms"] == f"{WANT_EXACT}/7"
         assert js[-2]["wer"] == pytest.approx(ref["WER"]) and js[-1]["post_wer"] == pytest.approx(ref["post_ST_wer"])
 
 

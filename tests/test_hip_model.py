@@ -485,10 +485,13 @@ def test_relprompt_full_size_vs_reference(golden):
     assert n_eq >= safe
 
 
-def test_llama3_8b_shape_vs_reference(golden):
+@pytest.mark.parametrize("name", ["llama3_shape", "llama3_shape_1536"])
+def test_llama3_8b_shape_vs_reference(golden, name):
     """BASELINE config 5's layer shape (Llama-3-8B, ger/config.py:801-818: d 4096, 32 heads / 8 groups, hs 128,
-    I 14336, V 128256, LoRA r 16) with 2 layers, bf16: prefill + decode logits and greedy ids against the reference."""
-    t, meta = golden("llama3_shape")
+    I 14336, V 128256, LoRA r 16) with 2 layers, bf16: prefill + decode logits and greedy ids against the reference — at
+    T = 96 and at the configuration's real prompt length, T = 1536 + 16 decode steps (`llama3_shape_1536`, VERDICT r03 #2:
+    24 key tiles of the prefill's online softmax, 49-50 32-key tiles per (sequence, group) in the fused decode attention)."""
+    t, meta = golden(name)
     cfg, m = build(meta)
     assert (cfg.n_embd, cfg.head_size, cfg.n_query_groups, cfg.intermediate_size, cfg.padded_vocab_size) == (4096, 128, 8, 14336, 128256)
     T, G = meta["T"], meta["G"]
@@ -496,17 +499,17 @@ def test_llama3_8b_shape_vs_reference(golden):
     with torch.no_grad():
         lg = m(t["idx"].view(1, -1).to(DEV), torch.arange(T, device=DEV))[0].float().cpu()
     m.reset_cache()
-    gate(lg[-4:, :4096], t["prefill_logits_last4_v4096"], t["prefill_logits_last4_v4096_fp32"], "llama3_shape prefill logits")
+    gate(lg[-4:, :4096], t["prefill_logits_last4_v4096"], t["prefill_logits_last4_v4096_fp32"], f"{name} prefill logits")
     u = ulp_diff(lg[-4:, -256:], t["prefill_logits_last4_tail256"].float(), 1.0)     # ulps at max(|a|, |b|, rms)
     rr_tail = rel_rms(lg[-4:, -256:], t["prefill_logits_last4_tail256"])
-    record_parity("llama3_shape.prefill_vocab_tail", max_ulp=u.max().item(), bit_exact_frac=(u == 0).float().mean().item(), rel_rms=rr_tail)
+    record_parity(f"{name}.prefill_vocab_tail", max_ulp=u.max().item(), bit_exact_frac=(u == 0).float().mean().item(), rel_rms=rr_tail)
     # the last 256 of the 128256 vocabulary rows (the lm_head's ragged last tile): as close to the reference as the first 4096
     assert rr_tail <= rel_rms(t["prefill_logits_last4_v4096"], t["prefill_logits_last4_v4096_fp32"])
     got = _teacher_forced(m, t["idx"], ids, T, G)
-    gate(got[:, :4096], t["step_logits_v4096"], t["step_logits_fp32_v4096"], "llama3_shape step logits")
+    gate(got[:, :4096], t["step_logits_v4096"], t["step_logits_fp32_v4096"], f"{name} step logits")
     assert float(margins.min()) >= 16, "fixture must be tie-free on every step"
     agree = got.argmax(-1) == ids[T:T + G]
     assert bool(agree.all())
     free = generate(m, t["idx"].to(DEV), T + G, temperature=0.2, top_k=1).cpu()
-    record_parity("llama3_shape.generate_ids", generated=G, min_margin_ulps=float(margins.min()), ids_equal_prefix=_equal_prefix(free[T:], ids[T:]))
+    record_parity(f"{name}.generate_ids", generated=G, min_margin_ulps=float(margins.min()), ids_equal_prefix=_equal_prefix(free[T:], ids[T:]))
     assert torch.equal(free, ids)

@@ -7,7 +7,7 @@ import math
 import pytest
 import torch
 
-from conftest import ulp_diff
+from conftest import ulp_diff, record_parity
 from dualhyp_amd.synth import uniform, stream_id
 
 pytestmark = pytest.mark.gpu
@@ -199,10 +199,22 @@ def test_linear_lora_down_projection_in_the_gemm(dev, M):
     res = U((M, d), 1.0, "fr").to(dev)
     # QKV-shaped: three segments at 2048 / 2304 (multiples of 256)
     want = ops.linear(x, w, epilogue=ops.EPI_LORA, xa=ops.linear(x, A48), lora_b=B16, lora_scale=2.0, splits=(d, d + kv))
-    assert torch.equal(ops.linear_lora(x, w, A48, B16, lora_scale=2.0, splits=(d, d + kv)), want)
+    got_qkv = ops.linear_lora(x, w, A48, B16, lora_scale=2.0, splits=(d, d + kv))
+    assert torch.equal(got_qkv, want)
     # attn.proj-shaped: one segment, fused residual, lora_scale 1 (its own code path in the epilogue)
     want = ops.linear(x, wp, epilogue=ops.EPI_LORA, xa=ops.linear(x, A16), lora_b=Bp, lora_scale=1.0, resid=res)
-    assert torch.equal(ops.linear_lora(x, wp, A16, Bp, lora_scale=1.0, resid=res), want)
+    got_proj = ops.linear_lora(x, wp, A16, Bp, lora_scale=1.0, resid=res)
+    assert torch.equal(got_proj, want)
+    # ... and DIRECTLY against the oracle's LoRA layers at this M (the in-GEMM form was tied to the
+    # oracle only through the two-launch form at M <= 517): ger/lora.py:367-402 (QKV, contiguous [Q|K|V] delta) and :159-166
+    # (proj) + the residual add of ger/model.py:313.  r = 16 here, so A48 / B16 are the reference's own A (3r, d) / B (N, r).
+    xc = x.cpu().unsqueeze(0)
+    want_o = O.lora_qkv_linear(xc, w.cpu(), A48.cpu(), B16.cpu(), 2.0, (d, kv, kv))[0]
+    mu, fr = check_ulp(got_qkv, want_o, 2, 0.002, f"in-GEMM qkv lora vs oracle, M={M}")
+    record_parity(f"linear_lora_in_gemm.qkv.M{M}", max_ulp=mu, differing_frac=fr)
+    want_o = (res.cpu().unsqueeze(0) + O.lora_linear(xc, wp.cpu(), A16.cpu(), Bp.cpu(), 1.0))[0]
+    mu, fr = check_ulp(got_proj, want_o, 2, 0.002, f"in-GEMM proj lora + resid vs oracle, M={M}")
+    record_parity(f"linear_lora_in_gemm.proj_resid.M{M}", max_ulp=mu, differing_frac=fr)
     # with the 8-wave kernel selected the library must take the two-launch path by itself
     from dualhyp_amd import _lib
     try:
@@ -447,10 +459,18 @@ def _attn_setup(dev, hs, n_head, n_groups, lens, pos0, s_max, seed):
     return q, kc, vt, ref
 
 
-@pytest.mark.parametrize("hs,n_head,n_groups", [(64, 32, 4), (64, 4, 2), (128, 8, 2)])
-def test_qkv_rope_cache_and_prefill_attention(dev, hs, n_head, n_groups):
+# "long": BASELINE config 5's context (10-best x 2 prompts of ~1.5k tokens, hs 128): 24-27 key tiles of the online
+# softmax per query block in the prefill kernel, 12+ split-KV partials in the decode kernels
+LONG_LENS = [1700, 65, 1536]
+
+
+@pytest.mark.parametrize("hs,n_head,n_groups,case", [(64, 32, 4, "short"), (64, 4, 2, "short"), (128, 8, 2, "short"), (128, 8, 2, "long"),
+                                                     (64, 8, 2, "long")])
+def test_qkv_rope_cache_and_prefill_attention(dev, hs, n_head, n_groups, case):
     from dualhyp_amd import ops
     lens, pos0, s_max = [70, 1, 33, 128], [0, 0, 0, 0], 192
+    if case == "long":
+        lens, pos0, s_max = LONG_LENS, [0, 0, 0], 1792
     q, kc, vt, ref = _attn_setup(dev, hs, n_head, n_groups, lens, pos0, s_max, seed=hs + n_head)
     qpk = n_head // n_groups
     t0 = 0
@@ -482,16 +502,24 @@ def test_qkv_rope_cache_and_prefill_attention(dev, hs, n_head, n_groups):
         # the reference's CPU kernel takes one KV block (<= 512 keys) against the final row max; this kernel
         # walks 64-key tiles with a running max, so P is rounded to bf16 at a different scale on
         # rows whose max moves: 1-ulp differences on up to ~15% of outputs at T = 128
-        assert u.max().item() <= 2.5 and (u > 0).float().mean().item() < 0.20, f"{u.max().item()} ulp, {(u > 0).float().mean().item():.2%} differ"
+        # (beyond 512 keys the reference's kernel walks 512-key blocks with a running max too, at block edges other than this
+        # kernel's 64-key ones; and a long row's output is an average of many values, small against the rms floor of the ulp)
+        frac = (u > 0).float().mean().item()
+        assert u.max().item() <= 2.5 and frac < (0.20 if case == "short" else 0.35), f"{u.max().item()} ulp, {frac:.2%} differ"
+        if case == "long":
+            record_parity(f"attention.prefill_vs_oracle_bf16.hs{hs}.T{n}", max_ulp=u.max().item(), differing_frac=frac,
+                          max_abs_hip_vs_fp32=err_hip, max_abs_oracle_vs_fp32=err_ref)
         t0 += n
 
 
-@pytest.mark.parametrize("hs,n_head,n_groups", [(64, 32, 4), (128, 8, 2)])
-def test_chunked_prefill_and_decode_attention(dev, hs, n_head, n_groups):
+@pytest.mark.parametrize("hs,n_head,n_groups,case", [(64, 32, 4, "short"), (128, 8, 2, "short"), (128, 8, 2, "long"), (64, 8, 2, "long")])
+def test_chunked_prefill_and_decode_attention(dev, hs, n_head, n_groups, case):
     """Prefill T-1 tokens, then one decode token per sequence at ragged positions; the decode
     kernel must agree with the prefill kernel run on the same cache and with fp32 attention."""
     from dualhyp_amd import ops
     lens, s_max = [100, 37, 64, 1, 129], 192
+    if case == "long":
+        lens, s_max = [1700, 1601, 1537, 129, 1536], 1792
     q, kc, vt, ref = _attn_setup(dev, hs, n_head, n_groups, lens, [0] * len(lens), s_max, seed=3)
     qpk = n_head // n_groups
     i32 = torch.int32
@@ -523,11 +551,12 @@ def test_chunked_prefill_and_decode_attention(dev, hs, n_head, n_groups):
         worst_pd = max(worst_pd, upd.max().item())
         assert upd.max().item() <= 2.0, f"seq {i}: decode and prefill kernels differ by {upd.max().item()} ulp on the same cache"
     from conftest import record_parity
-    record_parity(f"attention.decode_vs_oracle_bf16.hs{hs}", max_ulp=worst, max_ulp_decode_vs_prefill_kernel=worst_pd)
+    record_parity(f"attention.decode_vs_oracle_bf16.hs{hs}.{case}", max_ulp=worst, max_ulp_decode_vs_prefill_kernel=worst_pd, max_keys=max(lens))
 
 
-@pytest.mark.parametrize("hs,n_head,n_groups,r", [(64, 32, 4, 16), (64, 4, 2, 4), (128, 8, 2, 16)])
-def test_fused_decode_kernels(dev, hs, n_head, n_groups, r):
+@pytest.mark.parametrize("hs,n_head,n_groups,r,case", [(64, 32, 4, 16, "short"), (64, 4, 2, 4, "short"), (128, 8, 2, 16, "short"),
+                                                       (128, 8, 2, 16, "long"), (64, 8, 2, 16, "long")])
+def test_fused_decode_kernels(dev, hs, n_head, n_groups, r, case):
     """The 3 kernels of the fused decode layer against the oracle ops they replace: partial-sum GEMM with the
     LoRA A rows appended, fused LoRA-finish + rope + cache append + attention, LoRA-finish + residual + norm."""
     from dualhyp_amd import ops
@@ -540,6 +569,8 @@ def test_fused_decode_kernels(dev, hs, n_head, n_groups, r):
     N = d + 2 * kv
     lens = [40, 1, 97, 64, 33]                      # kv_len per sequence INCLUDING the new token
     B, s_max, s = len(lens), 128, 2.0
+    if case == "long":                              # config 5's context: 50+ 32-key tiles per (sequence, group), VERDICT r03 #2
+        lens, s_max = [1601, 1, 1537, 1700, 129], 1792
     xn = U((B, d), 1.0, "fx")
     W, A, Bm = U((N, d), 0.05, "fw"), U((3 * r, d), 1 / math.sqrt(d), "fa"), U((N, r), 0.05, "fb")
     A48 = torch.zeros(48, d, dtype=torch.bfloat16)
@@ -582,6 +613,9 @@ def test_fused_decode_kernels(dev, hs, n_head, n_groups, r):
         assert err <= max(2 * err_ref, 2e-2), f"fused decode attention seq {i}: err {err} vs reference-kernel err {err_ref}"
         u = ulp_diff(got, want, 1.0)          # the new token's q/k/v may already differ by 1 ulp from the oracle's (K-split sums)
         assert u.max().item() <= 3.0 and u.mean().item() <= 0.5, f"fused decode attention seq {i}: max {u.max().item()} / mean {u.mean().item():.2f} ulp vs the oracle's bf16 SDPA"
+        if case == "long":
+            record_parity(f"attention.fused_decode_vs_oracle_bf16.hs{hs}.keys{n}", max_ulp=u.max().item(), mean_ulp=u.mean().item(),
+                          max_abs_hip_vs_fp32=err, max_abs_oracle_vs_fp32=err_ref)
     # ---- proj LoRA finish + residual + norm
     att = U((B, d), 1.0, "fatt")
     Wp, Ap, Bp = U((d, d), 0.05, "fwp"), U((r, d), 1 / math.sqrt(d), "fap"), U((d, r), 0.05, "fbp")

@@ -585,3 +585,54 @@ def test_fit_with_packing_matches_fit_without():
     drift = (s4[1] - s1[1]).pow(2).mean().sqrt().item()
     record_parity("fit_packing.tiny", rms_update=upd, rms_packed_vs_launch_by_launch=drift, max_loss_diff_first_window=max(abs(a - b) for a, b in zip(l4[:8], l1[:8])))
     assert drift <= 0.25 * upd, f"packed and launch-by-launch trajectories drift apart: {drift:.3e} vs an update of {upd:.3e}"
+
+
+def test_graph_cache_is_bounded_and_shares_one_pool():
+    """ragged data make tens of (padded length, head rows) graph keys.  All graphs capture into ONE memory
+    pool and the cache is an LRU of `max_graphs` entries: device memory stays bounded however many keys arrive, an evicted key
+    is captured again and gives the bits it gave the first time, and an undercounted `n_targets` is refused at capture."""
+    from dualhyp_amd import GPT, Config
+    from dualhyp_amd.synth import synth_state_dict
+    from dualhyp_amd.train import prepare_for_training, GraphedTrainStep
+    from dualhyp_amd.finetune import FlatGradBucket
+    cfg = Config.from_name("parity-block", r=16, alpha=16, dropout=0.0, to_query=True, to_key=True, to_value=True, to_projection=True)
+    m = GPT(cfg).to(device=DEV, dtype=torch.bfloat16)
+    m.load_state_dict(synth_state_dict(cfg, seed=5, device=DEV, norm_jitter=0.25))
+    m.train()
+    params = prepare_for_training(m)
+    bucket = FlatGradBucket(params)
+    step = GraphedTrainStep(m, bucket, max_graphs=3)
+    g = torch.Generator().manual_seed(8)
+    P = 4
+
+    def batch(T, n_resp):
+        ids = torch.randint(3, cfg.padded_vocab_size, (P, T), generator=g)
+        labels = ids.clone()
+        labels[:, : T - n_resp] = -1
+        return ids.to(DEV), labels.to(DEV)
+
+    keys = [(64 * k, r) for k in range(2, 9) for r in (20, 90)]          # 14 distinct (T_pad, n_rows) keys
+    first, reserved = {}, []
+    for T, r in keys:
+        ids, labels = batch(T, r)
+        bucket.zero()
+        loss = step(ids, labels, 0.25, n_targets=P * r)
+        first[(T, r)] = (ids, labels, loss.clone(), bucket.flat.clone())
+        torch.cuda.synchronize()
+        reserved.append(torch.cuda.memory_reserved())
+        assert len(step._graphs) <= 3
+    assert step.captures == len(keys)
+    # after the LARGEST key of the first three the pool only grows by what a larger graph needs: the 14 graphs do not add up
+    act = lambda T: P * T * 2 * cfg.n_embd * 2       # a loose lower bound of one graph's saved activations (bytes)
+    assert reserved[-1] - reserved[2] < 0.5 * sum(act(T) for T, _ in keys[3:]) + (256 << 20), reserved
+    # an evicted key comes back: captured again, same bits
+    T, r = keys[0]
+    ids, labels, loss0, flat0 = first[keys[0]]
+    assert (P, T, m.cpu_rsqrt_vec_width, 256) not in step._graphs
+    bucket.zero()
+    loss = step(ids, labels, 0.25, n_targets=P * r)
+    assert step.captures == len(keys) + 1 and torch.equal(loss, loss0) and torch.equal(bucket.flat, flat0)
+    # an undercount is refused where the key is captured (512 targets, 256 head rows)
+    ids, labels = batch(192, 128)
+    with pytest.raises(ValueError, match="n_targets"):
+        step(ids, labels, 0.25, n_targets=200)

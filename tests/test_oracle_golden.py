@@ -335,9 +335,11 @@ def test_relprompt_full_size(golden):
 
 
 @SLOW
-def test_llama3_shape(golden):
-    """BASELINE config 5's layer shape (Llama-3-8B: hs 128, 8 groups, I 14336, V 128256), 2 layers."""
-    t, meta = golden("llama3_shape")
+@pytest.mark.parametrize("name", ["llama3_shape", "llama3_shape_1536"])
+def test_llama3_shape(golden, name):
+    """BASELINE config 5's layer shape (Llama-3-8B: hs 128, 8 groups, I 14336, V 128256), 2 layers: at T = 96 and at the
+    configuration's own prompt length T = 1536 (VERDICT r03 #2)."""
+    t, meta = golden(name)
     cfg = Config(**meta["config"])
     sd = synth_state_dict(cfg, seed=meta["seed"], embed_scale=meta["embed_scale"], head_tie=meta["head_tie"])
     m = O.OracleGPT(cfg, sd)
