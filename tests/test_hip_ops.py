@@ -505,10 +505,20 @@ def test_qkv_rope_cache_and_prefill_attention(dev, hs, n_head, n_groups, case):
         # (beyond 512 keys the reference's kernel walks 512-key blocks with a running max too, at block edges other than this
         # kernel's 64-key ones; and a long row's output is an average of many values, small against the rms floor of the ulp)
         frac = (u > 0).float().mean().item()
-        assert u.max().item() <= 2.5 and frac < (0.20 if case == "short" else 0.35), f"{u.max().item()} ulp, {frac:.2%} differ"
-        if case == "long":
-            record_parity(f"attention.prefill_vs_oracle_bf16.hs{hs}.T{n}", max_ulp=u.max().item(), differing_frac=frac,
-                          max_abs_hip_vs_fp32=err_hip, max_abs_oracle_vs_fp32=err_ref)
+        if case == "short":
+            assert u.max().item() <= 2.5 and frac < 0.20, f"{u.max().item()} ulp, {frac:.2%} differ"
+        else:
+            # At 1.5k keys neither bf16 kernel is "the" answer: each is 2-3 ulps from the fp32 result on its worst element, at
+            # different elements (their P roundings differ in every one of the 24-27 tiles), so they sit up to ~5 ulps apart.
+            # The gate is ACCURACY, in ulps against the fp32 truth: HIP's worst and mean error no larger than the reference
+            # kernel's (x1.25 / +0.5 ulp of slack), and the two bf16 results no further apart than their errors add up to.
+            u_ht, u_rt = ulp_diff(got, truth, 1.0), ulp_diff(want.float(), truth, 1.0)
+            record_parity(f"attention.prefill_vs_oracle_bf16.hs{hs}.T{n}", max_ulp_hip_vs_oracle=u.max().item(), differing_frac=frac,
+                          max_ulp_hip_vs_fp32=u_ht.max().item(), max_ulp_oracle_vs_fp32=u_rt.max().item(),
+                          mean_ulp_hip_vs_fp32=u_ht.mean().item(), mean_ulp_oracle_vs_fp32=u_rt.mean().item())
+            assert u_ht.max().item() <= 1.25 * u_rt.max().item() + 0.5 and u_ht.mean().item() <= 1.25 * u_rt.mean().item() + 0.02, \
+                f"T={n}: HIP {u_ht.max().item():.2f} / {u_ht.mean().item():.3f} ulp (max / mean) from fp32, reference kernel {u_rt.max().item():.2f} / {u_rt.mean().item():.3f}"
+            assert u.max().item() <= u_ht.max().item() + u_rt.max().item() + 1e-6
         t0 += n
 
 
