@@ -28,6 +28,7 @@
 #include "common.h"
 #include "gemm.h"
 
+int g_w4_fast_epi = 3;  // dh_set_tuning(24, bits): bit 0 the fused-QKV epilogue of full tiles in its v_dot2_f32_bf16 form (g256_epilogue_qkv_fast), bit 1 the same arithmetic in the LoRA / residual epilogues; 0 = the round-3 forms (A/B)
 int g_w4_persist = 1;   // dh_set_tuning(22, 0 | 1 | 2): the 4-wave kernel walks the tiles with one block per CU: never / where the epilogue loads nothing / always
 
 namespace {
@@ -35,10 +36,11 @@ namespace {
 constexpr int BT2 = 256;
 constexpr int BK = 64;
 constexpr int TILE_B = BT2 * BK * 2;   // 32 KiB
+constexpr int G256_VIMG_BYTES = 4 * 16 * (128 + 8) * 2;   // g256_epilogue_qkv_fast: [16 keys][HS + 8] bf16 per wave, HS <= 128
 
 #ifdef DH_G256_STAMPS   // diagnostic build only (tools/probe_gemm256.py): 100 MHz timestamps of wave 0 per block
-__device__ unsigned long long g_g256_stamps[8192 * 4];
-#define G256_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_g256_stamps[blockIdx.x * 4 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+__device__ unsigned long long g_g256_stamps[8192 * 16];
+#define G256_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_g256_stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 extern "C" int dh_debug_g256_stamps(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_g256_stamps), sizeof(g_g256_stamps)) == hipSuccess ? 0 : 1;
 }
@@ -358,6 +360,290 @@ __device__ __forceinline__ void g256_epilogue(const GemmArgs& a, f32x4 (&acc)[8]
             }
         }
     });
+}
+
+// ---- v_dot2_f32_bf16 as the epilogues' bf16 arithmetic (round 4) ---------------------------------------------------------------
+// D = S0.lo * S1.lo + S0.hi * S1.hi + S2 on packed bf16 pairs, f32 result: one VALU issue slot (5.3 cycles for a wave alone on its
+// SIMD, tools/valu_issue.hip — the price of a v_mul_f32), and what the eager-bf16 reference does between two rounding points is
+// exactly such a term:
+//   * a PRODUCT of two bf16 values: (x_e, x_e+1) . (c_e, 0) = x_e c_e — exact in f32 like v_mul_f32 on the expanded operands, with
+//     no expansion of x (the v_cvt_pk_bf16_f32 result is the operand) and the negation of rotate-half as a free source modifier;
+//   * the SUM of two bf16 values that sit in one register, (a, b) . (1, 1): v_cvt_pk_bf16_f32(acc, lora) IS (bf16(acc), bf16(lora)),
+//     so "round both, add" is two instructions.  The dot's internal sum is not the IEEE f32 sum when the exponents are > 16 apart,
+//     but ROUNDED TO BF16 (the next thing that happens to it at every use here) it is: tools/dot2_probe.hip, 2^31 operand pairs
+//     incl. every bf16 pattern against near and far exponents: 0 differences (profiles/r04_dot2_probe.txt).
+// Two consequences of the zero-padded second product: a non-finite x_e+1 turns x_e's product into NaN (0 * inf) — a row with an
+// inf / NaN in q or k is lost in the attention anyway — and the sign of an exactly-zero product is +0 (numerically equal).
+// HAZARD: on gfx90a+ a DOT instruction's result needs 3 wait states before another VALU instruction reads it (4 before one
+// overwrites it; LLVM GCNHazardRecognizer DotWriteDifferentVALURead / ...VALUWrite).  The compiler pads this only for instructions it
+// knows, and its own selection of the builtin is the accumulate form v_dot2c (D += ., i.e. a v_mov 0 per use), so the dots are
+// written as asm BLOCKS whose instruction order keeps every dot result >= 3 instructions away from its reader; each block ends
+// >= 4 instructions behind its last dot, and only v_cvt_pk results leave a block.  (First version: single-instruction asms, every
+// rotated value wrong on the GPU — v_cvt_pk read its dot operands one instruction behind them.)  Blocks only ever read VALU
+// results: MFMA results go through a compiler-visible v_cvt_pk first.
+#define DH_ONES_BF16X2 0x3f803f80u
+// y0 = cvt_pk(lo + hi of p0, of p1), y1 = cvt_pk(.. p2, .. p3), y2, y3 likewise from p4..p7: eight "round both, add", four packs
+__device__ __forceinline__ void dot2_sum8_pack(uint32_t (&p)[8], uint32_t& y0, uint32_t& y1, uint32_t& y2, uint32_t& y3) {
+    asm("v_dot2_f32_bf16 %0, %0, %12, 0\n\tv_dot2_f32_bf16 %1, %1, %12, 0\n\tv_dot2_f32_bf16 %2, %2, %12, 0\n\tv_dot2_f32_bf16 %3, %3, %12, 0\n\t"
+        "v_dot2_f32_bf16 %4, %4, %12, 0\n\tv_dot2_f32_bf16 %5, %5, %12, 0\n\tv_dot2_f32_bf16 %6, %6, %12, 0\n\tv_dot2_f32_bf16 %7, %7, %12, 0\n\t"
+        "v_cvt_pk_bf16_f32 %8, %0, %1\n\tv_cvt_pk_bf16_f32 %9, %2, %3\n\tv_cvt_pk_bf16_f32 %10, %4, %5\n\tv_cvt_pk_bf16_f32 %11, %6, %7"
+        : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]), "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3)
+        : "s"(DH_ONES_BF16X2));
+}
+// One half of the rotation of a 16-column tile pair (4 outputs per lane): out_e = bf16(a_e ca_e) + bf16(+-b_e cb_e), e = 0..3, with
+// a = (ax: e 0,1 | ay: e 2,3), b likewise, and per e the masked table operand (c, 0) for even e / (0, c) for odd e.  NEG: the second
+// product negated (rotate-half's -x2 sin).  8 products, 4 cvt_pk (= both roundings), 4 sums, 2 packs; the s_nop keeps the last sums
+// 3 wait states from their pack.
+template <bool NEG>
+__device__ __forceinline__ uint2 rope_half(uint32_t ax, uint32_t ay, uint32_t bx, uint32_t by, const uint32_t (&ca)[4], const uint32_t (&cb)[4]) {
+    uint32_t t0, t1, t2, t3, t4, t5, t6, t7, o0, o1;
+    if constexpr (NEG) {
+        asm("v_dot2_f32_bf16 %0, %10, %14, 0\n\tv_dot2_f32_bf16 %1, %12, %18, 0 neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"
+            "v_dot2_f32_bf16 %2, %10, %15, 0\n\tv_dot2_f32_bf16 %3, %12, %19, 0 neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"
+            "v_dot2_f32_bf16 %4, %11, %16, 0\n\tv_dot2_f32_bf16 %5, %13, %20, 0 neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"
+            "v_dot2_f32_bf16 %6, %11, %17, 0\n\tv_dot2_f32_bf16 %7, %13, %21, 0 neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"
+            "v_cvt_pk_bf16_f32 %0, %0, %1\n\tv_cvt_pk_bf16_f32 %2, %2, %3\n\tv_cvt_pk_bf16_f32 %4, %4, %5\n\tv_cvt_pk_bf16_f32 %6, %6, %7\n\t"
+            "v_dot2_f32_bf16 %1, %0, %22, 0\n\tv_dot2_f32_bf16 %3, %2, %22, 0\n\tv_dot2_f32_bf16 %5, %4, %22, 0\n\tv_dot2_f32_bf16 %7, %6, %22, 0\n\t"
+            "s_nop 1\n\tv_cvt_pk_bf16_f32 %8, %1, %3\n\tv_cvt_pk_bf16_f32 %9, %5, %7"
+            : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "=&v"(o0), "=&v"(o1)
+            : "v"(ax), "v"(ay), "v"(bx), "v"(by), "v"(ca[0]), "v"(ca[1]), "v"(ca[2]), "v"(ca[3]), "v"(cb[0]), "v"(cb[1]), "v"(cb[2]), "v"(cb[3]),
+              "s"(DH_ONES_BF16X2));
+    } else {
+        asm("v_dot2_f32_bf16 %0, %10, %14, 0\n\tv_dot2_f32_bf16 %1, %12, %18, 0\n\t"
+            "v_dot2_f32_bf16 %2, %10, %15, 0\n\tv_dot2_f32_bf16 %3, %12, %19, 0\n\t"
+            "v_dot2_f32_bf16 %4, %11, %16, 0\n\tv_dot2_f32_bf16 %5, %13, %20, 0\n\t"
+            "v_dot2_f32_bf16 %6, %11, %17, 0\n\tv_dot2_f32_bf16 %7, %13, %21, 0\n\t"
+            "v_cvt_pk_bf16_f32 %0, %0, %1\n\tv_cvt_pk_bf16_f32 %2, %2, %3\n\tv_cvt_pk_bf16_f32 %4, %4, %5\n\tv_cvt_pk_bf16_f32 %6, %6, %7\n\t"
+            "v_dot2_f32_bf16 %1, %0, %22, 0\n\tv_dot2_f32_bf16 %3, %2, %22, 0\n\tv_dot2_f32_bf16 %5, %4, %22, 0\n\tv_dot2_f32_bf16 %7, %6, %22, 0\n\t"
+            "s_nop 1\n\tv_cvt_pk_bf16_f32 %8, %1, %3\n\tv_cvt_pk_bf16_f32 %9, %5, %7"
+            : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "=&v"(o0), "=&v"(o1)
+            : "v"(ax), "v"(ay), "v"(bx), "v"(by), "v"(ca[0]), "v"(ca[1]), "v"(ca[2]), "v"(ca[3]), "v"(cb[0]), "v"(cb[1]), "v"(cb[2]), "v"(cb[3]),
+              "s"(DH_ONES_BF16X2));
+    }
+    return make_uint2(o0, o1);
+}
+
+// The fused-QKV epilogue of the 4-wave kernel for a FULL tile with the in-GEMM LoRA down-projection (the prefill of both model
+// shapes): LoRA finish, rope on the q / k heads, q -> q_out, k -> K cache, v -> V^T cache — the arithmetic of g256_epilogue's QKV
+// branch (= qkv_rope_cache_kernel, ger/model.py:216-259, 349-355; ger/lora.py:367-402), bit for bit, in ~340 instead of ~780 VALU
+// instructions per 16-row strip:
+//   * LoRA finish: p = cvt_pk(acc_e, lora_e) = (bf16(x W^T), bf16(x A^T B^T)); y_e = dot2_sum(p); packed y = cvt_pk(y_e, y_e+1) — 2.5
+//     instructions per element behind the accumulator read (was 5: two round trips f32 -> bf16 -> f32 and an add);
+//   * rope: the packed y pairs are the dot operands; cos / sin pairs are split ONCE per strip into (c, 0) / (0, c) masks shared by
+//     the wave's heads; per output element two products, one cvt_pk (= both roundings), one dot2_sum, half a final cvt_pk;
+//   * heads are classified (q / k / v, group, destination strides) once per tile, not per strip: no integer division in the strips;
+//   * V^T: when a strip's 16 rows are 16 consecutive positions of one slot from a multiple of 16 (every strip of a prompt whose
+//     packed start and cache position agree mod 16 — the benchmark's prompts), the strip's [16 keys][HS d] values go through a
+//     wave-private LDS image and come back transposed by ds_read_b64_tr_b16: a lane holds, for one d, keys {0..3, 8..11} or
+//     {4..7, 12..15} — the 8-key run of the cache's fragment order (common.h vfrag_off) — i.e. one 16-byte store instead of eight
+//     2-byte ones.  Other strips keep the scatter.
+// `vimg`: 4 KiB of LDS per wave (HS 128: [16][128 + 8] bf16).
+template <int HS>
+__device__ __forceinline__ void g256_epilogue_qkv_fast(const GemmArgs& a, f32x4 (&acc)[8][8], const int m0, const int n0, const int wn,
+                                                       const int wm, const int lane, const char* xs, char* vimg) {
+    constexpr int HALF = HS / 2, H2T = HS / 32, NH = 128 / HS, HT = HS / 16;      // tiles per half head, heads per wave, tiles per head
+    constexpr int VSTR = (HS + 8) * 2;                                            // bytes per key row of the V image (8-byte aligned rows)
+    const int frow = lane & 15, kg = lane >> 4;
+    const int mw0 = m0 + wm * 128, nw0 = n0 + wn * 128;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // ---- once per tile: LoRA B rows of the wave's 8 column tiles, positions / slots of its 8 row strips, head classes
+    bf16x8 lbv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int nn = nw0 + i * 16 + frow;
+        nn = nn < a.N ? nn : a.N - 1;                    // (a ragged last column tile: its heads are skipped below)
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(a.lora_b + (size_t)nn * 16 + (kg & 1) * 8);
+        lbv[i] = kg < 2 ? v : zero8;
+    }
+    const int qpk = a.n_head / a.n_groups;
+    int hg[NH], hj[NH];                                  // wave-uniform: group and index inside the group (0..qpk-1 q, qpk k, qpk+1 v)
+#pragma unroll
+    for (int hh = 0; hh < NH; ++hh) {
+        const int hidx = __builtin_amdgcn_readfirstlane((nw0 + hh * HS) / HS);
+        hg[hh] = hidx / (qpk + 2);
+        hj[hh] = hidx - hg[hh] * (qpk + 2);
+    }
+    const int cpair = (kg & 1) * 16 + (kg >> 1) * 8;     // this lane's 8 columns inside a 32-column pair after the lane swap
+    auto pair16 = [&](uint2 ta, uint2 tb) __attribute__((always_inline)) -> uint4 {
+        const auto rx = __builtin_amdgcn_permlane16_swap(ta.x, tb.x, false, false);
+        const auto ry = __builtin_amdgcn_permlane16_swap(ta.y, tb.y, false, false);
+        return make_uint4(rx[0], ry[0], rx[1], ry[1]);
+    };
+    // rope rows of a strip: per tile t of a half head c1 (first half), c2 (second half), s1, s2, 4 bf16 each
+    auto load_rope = [&](int pos, uint2 (&r)[4 * H2T]) __attribute__((always_inline)) {
+        const bf16_t* cp = a.rope_cos + (size_t)pos * HS + 4 * kg;
+        const bf16_t* sp = a.rope_sin + (size_t)pos * HS + 4 * kg;
+#pragma unroll
+        for (int t = 0; t < H2T; ++t) {
+            r[4 * t + 0] = *reinterpret_cast<const uint2*>(cp + 16 * t);
+            r[4 * t + 1] = *reinterpret_cast<const uint2*>(cp + HALF + 16 * t);
+            r[4 * t + 2] = *reinterpret_cast<const uint2*>(sp + 16 * t);
+            r[4 * t + 3] = *reinterpret_cast<const uint2*>(sp + HALF + 16 * t);
+        }
+    };
+    auto load_xf = [&](int j) __attribute__((always_inline)) -> bf16x8 {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(xs + (wm * 128 + j * 16 + frow) * 32 + (kg & 1) * 16);
+        return kg < 2 ? v : zero8;
+    };
+    auto load_pos = [&](int j, int& pos, int& slot) __attribute__((always_inline)) {
+        int mm = mw0 + (j < 8 ? j : 7) * 16 + frow;
+        mm = mm < a.M ? mm : a.M - 1;                    // rows past M (ragged last row band): computed like the last row, never stored
+        pos = a.tok_pos[mm];
+        slot = a.tok_slot[mm];
+    };
+    char* const vim = vimg + (wn * 2 + wm) * (16 * VSTR);
+    // ---- the 8 row strips as a LOOP: one copy of the strip's code (~700 instructions) stays in the instruction cache.  Unrolled
+    // (round 3's form, and this function's first version) the tile's epilogue is 50-100 KB of straight-line code executed once
+    // per tile — more than the 64 KB instruction cache two CUs share — and ran at ~18 cycles per instruction whatever it did
+    // (no MFMA, no loads, no stores: tools/probe_gemm256.py bit experiments, profiles/r04_probe_qkv_epilogue.txt): instruction
+    // fetch.  The accumulators need static register numbers, so a strip's 32 values are read behind a compare chain on j;
+    // positions / slots / rope rows / x.A^T fragments are software-pipelined through loop-carried registers.
+    int pos0, slot0, pos1, slot1;
+    uint2 rope0[4 * H2T];
+    load_pos(0, pos0, slot0);
+    load_pos(1, pos1, slot1);
+    load_rope(pos0, rope0);
+    bf16x8 xf0 = load_xf(0);
+    G256_STAMP(4);
+#pragma unroll 1
+    for (int j = 0; j < 8; ++j) {
+        // prefetch: position of strip j + 2, rope rows and x.A^T fragment of strip j + 1 (the last iterations re-load strip 7's)
+        int pos2, slot2;
+        load_pos(j + 2, pos2, slot2);
+        uint2 rope1[4 * H2T];
+        load_rope(pos1, rope1);
+        const bf16x8 xf1 = load_xf(j + 1 < 8 ? j + 1 : 7);
+        const int m = mw0 + j * 16 + frow, pos = pos0, slot = slot0;
+        const bool m_ok = m < a.M;
+        // this strip's 32 accumulator values per lane: static register indices behind a uniform compare chain
+        float av[8][4];
+        static_for<8>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int J = decltype(jc)::value;
+            if (j == J) {
+                // volatile: a plain copy is loop-invariant, and hoisted out of the loop all 256 values land in VGPRs at once (204 spilled)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float src = acc[i][J][e];
+                        float dst;
+                        if (i < 7) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(dst) : "a"(src));
+                        else asm volatile("v_mov_b32 %0, %1" : "=v"(dst) : "v"(src));
+                        av[i][e] = dst;
+                    }
+            }
+        });
+        // Pin the wait for this strip's rope rows HERE, on every path: a v head never reads them, and loads left pending across
+        // that branch make every later reuse of their registers a conservative s_waitcnt vmcnt(N) that, the counter being in
+        // order, also waits for the previous strip's stores.
+#pragma unroll
+        for (int k = 0; k < 4 * H2T; ++k) asm volatile("" : "+v"(rope0[k].x), "+v"(rope0[k].y));
+        // ---- LoRA finish: y[i] = the wave's 8 column tiles of this strip as packed bf16 (columns 4 kg .. 4 kg + 3 of tile i)
+        uint2 y[8];
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            uint32_t pk[8];                          // (bf16(acc), bf16(LoRA term)) of the 2 x 4 elements of tiles i, i + 1
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 l = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lbv[i + h], xf0, zero4, 0, 0, 0);
+                if (a.lora_scale == 1.f) {           // wave-uniform; alpha == r in both reference harnesses
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk[4 * h + e] = pack2bf(av[i + h][e], l[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk[4 * h + e] = pack2bf(av[i + h][e], rbf(l[e]) * a.lora_scale);
+                }
+            }
+            dot2_sum8_pack(pk, y[i].x, y[i].y, y[i + 1].x, y[i + 1].y);
+        }
+        // ---- cos / sin of the row as dot operands: [t][c1 c2 s1 s2][e]: (c, 0) for even e, (0, c) for odd e
+        uint32_t cm[H2T][4][4];
+#pragma unroll
+        for (int t = 0; t < H2T; ++t)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint2 r = rope0[4 * t + k];
+                cm[t][k][0] = r.x & 0xffffu; cm[t][k][1] = r.x & 0xffff0000u;
+                cm[t][k][2] = r.y & 0xffffu; cm[t][k][3] = r.y & 0xffff0000u;
+            }
+        // is this strip 16 consecutive positions of one slot from a multiple of 16?  (the V^T fast path; wave-uniform)
+        const int p0u = __builtin_amdgcn_readfirstlane(pos), s0u = __builtin_amdgcn_readfirstlane(slot);
+        const bool vfast = __builtin_amdgcn_ballot_w64(pos == p0u + frow && slot == s0u && m_ok) == ~0ull && (p0u & 15) == 0;
+#pragma unroll
+        for (int hh = 0; hh < NH; ++hh) {
+            const int t0 = hh * HT, g = hg[hh], jh = hj[hh];
+            if (nw0 + hh * HS >= a.N) continue;          // wave-uniform: a head past the last column
+            if (jh <= qpk) {
+                // ---- q or k head: rotate, then 16-byte stores of 8 consecutive columns per lane
+                uint2 p1[H2T], p2[H2T];
+#pragma unroll
+                for (int t = 0; t < H2T; ++t) {
+                    const uint2 x1 = y[t0 + t], x2 = y[t0 + H2T + t];
+                    // o1 = bf16(x1 c1) + bf16(-x2 s1), o2 = bf16(x2 c2) + bf16(x1 s2)   (ger/model.py:349-355, every product and sum rounded)
+                    p1[t] = rope_half<true>(x1.x, x1.y, x2.x, x2.y, cm[t][0], cm[t][2]);
+                    p2[t] = rope_half<false>(x2.x, x2.y, x1.x, x1.y, cm[t][1], cm[t][3]);
+                }
+                // destination of the lane's first 16 bytes, stride between the two halves of the head and between 32-column pairs
+                bf16_t* d0;
+                int d_half, d_pair;
+                if (jh < qpk) {
+                    d0 = a.q_out + ((size_t)m * a.n_head + g * qpk + jh) * HS + cpair;
+                    d_half = HALF;
+                    d_pair = 32;
+                } else {   // K cache, fragment order (common.h kfrag_off): 8 channels of one key are one 16-byte run
+                    d0 = a.k_cache + ((size_t)slot * a.n_groups + g) * a.s_max * HS + kfrag_off<HS>(pos, cpair);
+                    d_half = (HALF / 16) * 512;
+                    d_pair = 1024;
+                }
+#pragma unroll
+                for (int tp = 0; tp < H2T / 2; ++tp) {
+                    const uint4 w1 = pair16(p1[2 * tp], p1[2 * tp + 1]), w2 = pair16(p2[2 * tp], p2[2 * tp + 1]);   // wave-wide swaps: every lane
+                    if (m_ok) {
+                        *reinterpret_cast<uint4*>(d0 + tp * d_pair) = w1;
+                        *reinterpret_cast<uint4*>(d0 + d_half + tp * d_pair) = w2;
+                    }
+                }
+            } else if (vfast) {
+                // ---- v head, aligned strip: [16 keys][HS d] through the wave's LDS image, back transposed (4 keys x one d per read)
+#pragma unroll
+                for (int t = 0; t < HT; ++t) *reinterpret_cast<uint2*>(vim + frow * VSTR + (16 * t + 4 * kg) * 2) = y[t0 + t];
+                bf16_t* vd = a.vT_cache + ((size_t)s0u * a.n_groups + g) * HS * a.s_max;
+                const int tk = p0u >> 5, s2 = (p0u >> 4) & 1;
+                // lane (group kg, i = frow = 4 q + p): block rows 4 lh + q (and + 8), columns 16 ct + 4 p ..; receives column 16 ct + frow
+                const char* rd = vim + (frow >> 2) * VSTR + (frow & 3) * 8;
+                typedef __attribute__((ext_vector_type(4))) short s16x4;
+                typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+#pragma unroll
+                for (int u = 0; u < HT / 4; ++u) {
+                    const int ct = kg + 4 * u, dd = 16 * ct + frow;
+#pragma unroll
+                    for (int lh = 0; lh < 2; ++lh) {
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(rd + (4 * lh) * VSTR + ct * 32));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(rd + (4 * lh + 8) * VSTR + ct * 32));
+                        const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+                        const size_t off = ((size_t)(((tk * (HS / 32) + (dd >> 5)) * 2 + s2) * 2 + lh) * 32 + (dd & 31)) * 8;
+                        *reinterpret_cast<uint4*>(vd + off) = make_uint4(l2.x, l2.y, h2.x, h2.y);
+                    }
+                }
+            } else if (m_ok) {
+                bf16_t* vd = a.vT_cache + ((size_t)slot * a.n_groups + g) * HS * a.s_max;
+#pragma unroll
+                for (int t = 0; t < HT; ++t) {
+                    const uint2 v = y[t0 + t];
+                    vd[vfrag_off<HS>(pos, 16 * t + 4 * kg + 0)] = (bf16_t)(v.x & 0xffffu);
+                    vd[vfrag_off<HS>(pos, 16 * t + 4 * kg + 1)] = (bf16_t)(v.x >> 16);
+                    vd[vfrag_off<HS>(pos, 16 * t + 4 * kg + 2)] = (bf16_t)(v.y & 0xffffu);
+                    vd[vfrag_off<HS>(pos, 16 * t + 4 * kg + 3)] = (bf16_t)(v.y >> 16);
+                }
+            }
+        }
+        // rotate the software pipeline
+        pos0 = pos1; slot0 = slot1; pos1 = pos2; slot1 = slot2;
+        xf0 = xf1;
+#pragma unroll
+        for (int k = 0; k < 4 * H2T; ++k) rope0[k] = rope1[k];
+    }
 }
 
 template <int EPI, bool RESID, int PIPE>
@@ -886,8 +1172,17 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
             first_stages();
         }
         G256_STAMP(2);
-        if (m0 + BT2 <= a.M && n0 + (EPI == DH_EPI_SWIGLU ? 128 : BT2) <= a.N) g256_epilogue<EPI, RESID, 8, true, XA>(a, acc, m0, n0, wn, wm, lane, xs_img);
-        else g256_epilogue<EPI, RESID, 8, false, XA>(a, acc, m0, n0, wn, wm, lane, xs_img);
+        const bool full = m0 + BT2 <= a.M && n0 + (EPI == DH_EPI_SWIGLU ? 128 : BT2) <= a.N;
+        if constexpr (EPI == DH_EPI_QKV && XA) {
+            // the fused-QKV kernel with the in-GEMM LoRA down-projection has ONE epilogue, ragged tiles included: a second one in the
+            // same kernel costs the register allocator's spill decisions in the code both share (51 scratch accesses per tile behind the K loop)
+            char* vimg = smem + 2 * BUF + 256 * 32;
+            if (a.hs == 64) g256_epilogue_qkv_fast<64>(a, acc, m0, n0, wn, wm, lane, xs_img, vimg);
+            else g256_epilogue_qkv_fast<128>(a, acc, m0, n0, wn, wm, lane, xs_img, vimg);
+        } else {
+            if (full) g256_epilogue<EPI, RESID, 8, true, XA>(a, acc, m0, n0, wn, wm, lane, xs_img);
+            else g256_epilogue<EPI, RESID, 8, false, XA>(a, acc, m0, n0, wn, wm, lane, xs_img);
+        }
         G256_STAMP(3);
         if (!more) break;
         vb = vb_next;
@@ -915,7 +1210,8 @@ inline int g256_cu_count() {
 template <int EPI, bool RESID, bool PERSIST, bool XA = false>
 int launch_w4p(const GemmArgs& a, hipStream_t s) {
     auto kfn = gemm_nt256w4_kernel<EPI, RESID, PERSIST, XA>;
-    constexpr int lds = 4 * TILE_B + (XA ? 2 * 2048 + 256 * 32 : 0);     // XA: + 16 rows of A per stage + the [256][16] image
+    // XA: + 16 rows of A per stage + the [256][16] x.A^T image; fused QKV: + the four waves' V images (g256_epilogue_qkv_fast)
+    constexpr int lds = 4 * TILE_B + (XA ? 2 * 2048 + 256 * 32 : 0) + (XA && EPI == DH_EPI_QKV ? G256_VIMG_BYTES : 0);
     DH_MAX_LDS_ONCE(kfn, lds);
     int blocks = a.nb_n * a.nb_m;
     if (PERSIST) blocks = blocks < g256_cu_count() ? blocks : g256_cu_count();   // one block per CU walks the tiles
@@ -986,6 +1282,7 @@ bool dh_linear_256_xa_ok(const GemmArgs& a, int epilogue) {
 
 int dh_linear_256(GemmArgs a, int epilogue, hipStream_t s) {
     a.gm = g_gemm_gm > 0 ? g_gemm_gm : 4;
+    a.fast_epi = g_w4_fast_epi;
     a.nb_m = cdiv(a.M, BT2);
     a.nb_n = (epilogue == DH_EPI_SWIGLU) ? cdiv(a.N, 128) : cdiv(a.N, BT2);
     switch (epilogue) {

@@ -16,15 +16,17 @@ rn = lambda *s: (torch.randn(*s, device=D, generator=g) * 0.05).bfloat16()
 x, act = rn(M, d), rn(M, I)
 W1, W2, Wm = rn(I, d), rn(I, d), rn(d, I)
 def stamps(n):
-    buf = np.zeros(8192 * 4, dtype=np.uint64)
+    buf = np.zeros(8192 * 16, dtype=np.uint64)
     assert raw.dh_debug_g256_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
-    return buf.reshape(8192, 4)[:n].astype(np.int64)
+    return buf.reshape(8192, 16)[:n].astype(np.int64)
 import os
 lib.dh_set_tuning(1, int(os.environ.get("G256_VARIANT", "5")))      # 1: 8-wave ping-pong, 5: 4-wave full-line
 lib.dh_set_tuning(22, 0)     # per-tile launches: a block = a tile
 H, G, hs, S = 32, 4, 64, 512
 Wq, Wp = rn(2560, d), rn(d, d)
 xa48, xa16, Bq, Bp = rn(M, 48), rn(M, 16), rn(2560, 16), rn(d, 16)
+A48, A16 = rn(48, d), rn(16, d)
+lib.dh_set_tuning(24, int(os.environ.get("G256_FAST_EPI", "3")))   # bit 0 / 1: the v_dot2 QKV / LoRA-residual epilogues (0: round-3 forms)
 cos, sin = rn(S, hs), rn(S, hs)
 nseq = M // S
 kc = torch.zeros(nseq, G, S, hs, device=D, dtype=torch.bfloat16); vt = torch.zeros(nseq, G, hs, S, device=D, dtype=torch.bfloat16)
@@ -32,8 +34,8 @@ tok_slot = torch.arange(nseq, device=D, dtype=torch.int32).repeat_interleave(S)
 tok_pos = torch.arange(S, device=D, dtype=torch.int32).repeat(nseq)
 for (nm, fn, nblk) in (("SwiGLU (K 2048)", lambda: ops.linear(x, W1, epilogue=ops.EPI_SWIGLU, w2=W2), 128 * 44),
                        ("mlp proj + residual (K 5632)", lambda: ops.linear(act, Wm, resid=x), 128 * 8),
-                       ("QKV + LoRA + rope + cache append", lambda: ops.linear_qkv_rope_cache(x, Wq, cos, sin, tok_slot, tok_pos, kc, vt, H, G, xa=xa48, lora_b=Bq), 128 * 10),
-                       ("attn proj + LoRA + residual", lambda: ops.linear(x, Wp, epilogue=ops.EPI_LORA, xa=xa16, lora_b=Bp, lora_scale=1.0, splits=(d, d), resid=x), 128 * 8)):
+                       ("QKV + LoRA + rope + cache append", lambda: ops.linear_qkv_lora_rope_cache(x, Wq, A48, Bq, cos, sin, tok_slot, tok_pos, kc, vt, H, G), 128 * 10),
+                       ("attn proj + LoRA + residual", lambda: ops.linear_lora(x, Wp, A16, Bp, lora_scale=1.0, resid=x), 128 * 8)):
     for _ in range(2): fn()
     torch.cuda.synchronize()
     st = stamps(nblk)
@@ -44,5 +46,12 @@ for (nm, fn, nblk) in (("SwiGLU (K 2048)", lambda: ops.linear(x, W1, epilogue=op
         v = seg[:, j]
         print(f"   {n:32s} median {np.median(v):6.2f}  p10 {np.percentile(v, 10):6.2f}  p90 {np.percentile(v, 90):6.2f} us")
     # gap between consecutive tiles on the same CU cannot be read from block ids; estimate from occupancy:
+    if nm.startswith("QKV") and st[:, 4].max() > 0:      # the fast fused-QKV epilogue's own stamps: set-up done, then the start of each 16-row strip
+        inner = np.stack([st[:, 4] - st[:, 2]] + [st[:, 5 + k] - st[:, 4 + k] for k in range(8)] + [st[:, 3] - st[:, 12]], 1) * 0.01
+        print("   fast QKV epilogue, median us: loop end -> set-up issued, set-up -> strip 0, strips 0..6, strip 7 -> end:", np.round(np.median(inner, 0), 2).tolist())
+        print("   G256_FAST_EPI bit 7: strip 3 start -> pair 0 -> pair 1 -> pair 2 done, median us:", np.round(np.median(np.stack([st[:, 13] - st[:, 8], st[:, 14] - st[:, 13], st[:, 15] - st[:, 14]], 1) * 0.01, 0), 2).tolist())
+        print("   slots 13 -> 14 (G256_FAST_EPI bit 6: 32 bare accumulator reads) median us:", float(np.median((st[:, 14] - st[:, 13]) * 0.01)))
+        sub = np.stack([st[:, 13] - st[:, 8], st[:, 14] - st[:, 13], st[:, 15] - st[:, 14], st[:, 9] - st[:, 15]], 1) * 0.01
+        print("   strip 3, median us: LoRA finish, masks, first head (rope + stores), second head:", np.round(np.median(sub, 0), 2).tolist())
     busy = seg[:, 3].sum() / 256
     print(f"   sum of tile times / 256 CUs = {busy:.1f} us of the {(st[:, 3].max() - t0) * 0.01:.1f} us span")
