@@ -438,7 +438,7 @@ __device__ __forceinline__ uint2 rope_half(uint32_t ax, uint32_t ay, uint32_t bx
 //     {4..7, 12..15} — the 8-key run of the cache's fragment order (common.h vfrag_off) — i.e. one 16-byte store instead of eight
 //     2-byte ones.  Other strips keep the scatter.
 // `vimg`: 4 KiB of LDS per wave (HS 128: [16][128 + 8] bf16).
-template <int HS>
+template <int HS, bool SCALE1>
 __device__ __forceinline__ void g256_epilogue_qkv_fast(const GemmArgs& a, f32x4 (&acc)[8][8], const int m0, const int n0, const int wn,
                                                        const int wm, const int lane, const char* xs, char* vimg) {
     constexpr int HALF = HS / 2, H2T = HS / 32, NH = 128 / HS, HT = HS / 16;      // tiles per half head, heads per wave, tiles per head
@@ -516,11 +516,21 @@ __device__ __forceinline__ void g256_epilogue_qkv_fast(const GemmArgs& a, f32x4 
         const bf16x8 xf1 = load_xf(j + 1 < 8 ? j + 1 : 7);
         const int m = mw0 + j * 16 + frow, pos = pos0, slot = slot0;
         const bool m_ok = m < a.M;
-        // this strip's 32 accumulator values per lane: static register indices behind a uniform compare chain
+        // the strip's eight LoRA MFMAs (rank 16 zero-padded to K = 32) back to back, straight into VGPRs: through the builtin the
+        // compiler serialises them on one AGPR quad (MFMA, s_nop, four v_accvgpr_read, eight times).  The accumulator reads
+        // below (>= 32 VALU instructions) stand between the last MFMA and the first use of a result.
+        f32x4 lora[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            // (s_nop 1: a VALU-written operand — the pipeline's xf0 = xf1 copy — in front of an MFMA the compiler cannot see)
+            if (i == 0) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(lora[i]) : "v"(lbv[i]), "v"(xf0));
+            else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=v"(lora[i]) : "v"(lbv[i]), "v"(xf0));
+        }
+        // this strip's 32 accumulator values per lane: static register indices behind a uniform compare tree on j
         float av[8][4];
-        static_for<8>([&](auto jc) __attribute__((always_inline)) {
+        auto read_acc = [&](auto jc) __attribute__((always_inline)) {
             constexpr int J = decltype(jc)::value;
-            if (j == J) {
+            {
                 // volatile: a plain copy is loop-invariant, and hoisted out of the loop all 256 values land in VGPRs at once (204 spilled)
 #pragma unroll
                 for (int i = 0; i < 8; ++i)
@@ -533,7 +543,15 @@ __device__ __forceinline__ void g256_epilogue_qkv_fast(const GemmArgs& a, f32x4 
                         av[i][e] = dst;
                     }
             }
-        });
+        };
+        if (j < 4) {
+            if (j < 2) { if (j == 0) read_acc(std::integral_constant<int, 0>{}); else read_acc(std::integral_constant<int, 1>{}); }
+            else { if (j == 2) read_acc(std::integral_constant<int, 2>{}); else read_acc(std::integral_constant<int, 3>{}); }
+        } else {
+            if (j < 6) { if (j == 4) read_acc(std::integral_constant<int, 4>{}); else read_acc(std::integral_constant<int, 5>{}); }
+            else { if (j == 6) read_acc(std::integral_constant<int, 6>{}); else read_acc(std::integral_constant<int, 7>{}); }
+        }
+        asm volatile("s_nop 7" ::: "memory");          // the last MFMA is >= 32 instructions back; this covers a short path whatever the schedule
         // Pin the wait for this strip's rope rows HERE, on every path: a v head never reads them, and loads left pending across
         // that branch make every later reuse of their registers a conservative s_waitcnt vmcnt(N) that, the counter being in
         // order, also waits for the previous strip's stores.
@@ -546,13 +564,12 @@ __device__ __forceinline__ void g256_epilogue_qkv_fast(const GemmArgs& a, f32x4 
             uint32_t pk[8];                          // (bf16(acc), bf16(LoRA term)) of the 2 x 4 elements of tiles i, i + 1
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const f32x4 l = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lbv[i + h], xf0, zero4, 0, 0, 0);
-                if (a.lora_scale == 1.f) {           // wave-uniform; alpha == r in both reference harnesses
+                const f32x4 l = lora[i + h];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) pk[4 * h + e] = pack2bf(av[i + h][e], l[e]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) pk[4 * h + e] = pack2bf(av[i + h][e], rbf(l[e]) * a.lora_scale);
+                for (int e = 0; e < 4; ++e) {
+                    // SCALE1: lora_scale == 1 (alpha == r, both reference harnesses): bf16(bf16(l) * 1) is bf16(l)
+                    if constexpr (SCALE1) pk[4 * h + e] = pack2bf(av[i + h][e], l[e]);
+                    else pk[4 * h + e] = pack2bf(av[i + h][e], rbf(l[e]) * a.lora_scale);
                 }
             }
             dot2_sum8_pack(pk, y[i].x, y[i].y, y[i + 1].x, y[i + 1].y);
@@ -1177,8 +1194,13 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
             // the fused-QKV kernel with the in-GEMM LoRA down-projection has ONE epilogue, ragged tiles included: a second one in the
             // same kernel costs the register allocator's spill decisions in the code both share (51 scratch accesses per tile behind the K loop)
             char* vimg = smem + 2 * BUF + 256 * 32;
-            if (a.hs == 64) g256_epilogue_qkv_fast<64>(a, acc, m0, n0, wn, wm, lane, xs_img, vimg);
-            else g256_epilogue_qkv_fast<128>(a, acc, m0, n0, wn, wm, lane, xs_img, vimg);
+            if (a.hs == 64) {
+                if (a.lora_scale == 1.f) g256_epilogue_qkv_fast<64, true>(a, acc, m0, n0, wn, wm, lane, xs_img, vimg);
+                else g256_epilogue_qkv_fast<64, false>(a, acc, m0, n0, wn, wm, lane, xs_img, vimg);
+            } else {
+                if (a.lora_scale == 1.f) g256_epilogue_qkv_fast<128, true>(a, acc, m0, n0, wn, wm, lane, xs_img, vimg);
+                else g256_epilogue_qkv_fast<128, false>(a, acc, m0, n0, wn, wm, lane, xs_img, vimg);
+            }
         } else {
             if (full) g256_epilogue<EPI, RESID, 8, true, XA>(a, acc, m0, n0, wn, wm, lane, xs_img);
             else g256_epilogue<EPI, RESID, 8, false, XA>(a, acc, m0, n0, wn, wm, lane, xs_img);

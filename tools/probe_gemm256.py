@@ -5,6 +5,7 @@ last stamp, so the gap to the NEXT tile's start on the same CU is part of the ep
 import ctypes, sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import os
 import numpy as np, torch
 from dualhyp_amd import ops, _lib
 lib = _lib.load()
@@ -16,9 +17,12 @@ rn = lambda *s: (torch.randn(*s, device=D, generator=g) * 0.05).bfloat16()
 x, act = rn(M, d), rn(M, I)
 W1, W2, Wm = rn(I, d), rn(I, d), rn(d, I)
 def stamps(n):
+    slots = int(os.environ.get("G256_SLOTS", "16"))          # 4: a library built from round 3's gemm256.hip
     buf = np.zeros(8192 * 16, dtype=np.uint64)
     assert raw.dh_debug_g256_stamps(buf.ctypes.data_as(ctypes.c_void_p)) == 0
-    return buf.reshape(8192, 16)[:n].astype(np.int64)
+    out = np.zeros((8192, 16), dtype=np.int64)
+    out[:, :slots] = buf[:8192 * slots].reshape(8192, slots).astype(np.int64)
+    return out[:n]
 import os
 lib.dh_set_tuning(1, int(os.environ.get("G256_VARIANT", "5")))      # 1: 8-wave ping-pong, 5: 4-wave full-line
 lib.dh_set_tuning(22, 0)     # per-tile launches: a block = a tile
