@@ -138,53 +138,108 @@ __global__ __launch_bounds__(WN * 128) void gemm_dt_kernel(DtArgs a) {
     f32x4 pairacc[MODE == 0 ? 4 : 1][MODE == 0 ? 4 : 1];   // MODE 0: the open pair's first slice
     int seg_idx = 0;
 
+    auto fold_segment = [&](bool last) __attribute__((always_inline)) {     // end of a chain segment: fold it in, in order
+        if (MODE == 0) {
+            // the partial-sum family's order: (s0 + s1) + (s2 + s3) + ... — slices in adjacent pairs, pair sums in
+            // index order; an unpaired last slice is added on its own
+            const bool second = seg_idx & 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (second) tot[i][j] += pairacc[i][j] + cur[i][j];
+                    else if (last) tot[i][j] += cur[i][j];
+                    else pairacc[i][j] = cur[i][j];
+                    cur[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            ++seg_idx;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    tot[i][j] += cur[i][j];
+                    cur[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+        }
+    };
+    int in_seg = 0;
+    if constexpr (WN == 4 && NSTAGE == 3) {
+    // ---- 8-wave tile, round 4: fragment reads one PHASE ahead of their MFMAs ("LDS-DMA fill and MFMA add up
+    // instead of overlapping" — every iteration began with its 16 ds_read_b128 and their latency in front of the matrix pipe, both
+    // waves of a SIMD in step).  An iteration (one 64-deep stage kt) is two phases around ONE barrier:
+    //   phase 1: read F1 <- stage kt (second k-step) | x pieces of stage kt+2 | 16 MFMAs on F0 | lgkmcnt(0), vmcnt: stage kt+1 landed | barrier
+    //   phase 2: read F0 <- stage kt+1 (first k-step) | W pieces of stage kt+3 -> the slot of stage kt | 16 MFMAs on F1 | segment fold
+    // Slot of stage kt is free behind the barrier of iteration kt: its F0 reads were consumed in phase 1, its F1 reads waited for
+    // (lgkmcnt(0)) in front of that barrier, by every wave.  Stage kt+1 is read (F0, phase 2) behind the same barrier, in front of
+    // which every wave waited for its own pieces of it.  Same MFMAs in the same order per accumulator: same bits.
+    //   pieces in flight at the wait of iteration kt: W (4) of stage kt+2 [phase 2 of kt-1] + x (NB) of stage kt+2 [phase 1 of kt] = PER
+    auto stage_w = [&](int kt) __attribute__((always_inline)) {
+        char* sA = smem + (kt % NSTAGE) * STAGE;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(srcA[j] + kt * BKD, sA + (wave * 4 + j) * 1024);
+    };
+    auto stage_x = [&](int kt) __attribute__((always_inline)) {
+        char* sB = smem + (kt % NSTAGE) * STAGE + ASZ;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) glds16(srcB[j] + kt * BKD, sB + (wave * NB + j) * 1024);
+    };
+    auto read_frags = [&](int kt, int ks, bf16x8 (&fa)[4], bf16x8 (&fb)[4]) __attribute__((always_inline)) {
+        const char* sA = smem + (kt % NSTAGE) * STAGE;
+        const char* sB = sA + ASZ;
+        const int co = ((ks * 4 + kg) ^ sw) << 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa[i] = *reinterpret_cast<const bf16x8*>(sA + offA + i * 2048 + co);
+            fb[i] = *reinterpret_cast<const bf16x8*>(sB + offB + i * 2048 + co);
+        }
+    };
+    auto mma = [&](const bf16x8 (&fa)[4], const bf16x8 (&fb)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cur[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], cur[i][j], 0, 0, 0);
+    };
+    // prologue: stages 0 and 1 whole, W of stage 2; stage 0 waited for (stage 1 + the W pieces of 2 stay in flight)
+    stage(0);
+    if (1 < nk) stage(1);
+    if (2 < nk) stage_w(2);
+    if (2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER + 4) : "memory");
+    else if (1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    bf16x8 fa0[4], fb0[4], fa1[4], fb1[4];
+    read_frags(0, 0, fa0, fb0);
+    for (int kt = 0; kt < nk; ++kt) {
+        // ---- phase 1
+        read_frags(kt, 1, fa1, fb1);
+        if (kt + 2 < nk) stage_x(kt + 2);
+        mma(fa0, fb0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 2
+        if (kt + 1 < nk) read_frags(kt + 1, 0, fa0, fb0);
+        if (kt + 3 < nk) stage_w(kt + 3);
+        mma(fa1, fb1);
+        if (++in_seg == seg_kt || kt + 1 == nk) {
+            in_seg = 0;
+            fold_segment(kt + 1 == nk);
+        }
+    }
+    } else {
     // prologue: NSTAGE-1 stages requested, the first one waited for
 #pragma unroll
     for (int p = 0; p < NSTAGE - 1; ++p)
         if (p < nk) stage(p);
     wait_next((nk < NSTAGE - 1 ? nk : NSTAGE - 1) - 1);
     __builtin_amdgcn_s_barrier();
-    int in_seg = 0;
     for (int kt = 0; kt < nk; ++kt) {
         // ring slot (kt+NSTAGE-1) % NSTAGE was last read in iteration kt-1, which ended with a barrier
         const bool pre = kt + NSTAGE - 1 < nk;
         const char* sA = smem + (kt % NSTAGE) * STAGE;
         const char* sB = sA + ASZ;
-        if constexpr (WN == 4) {
-        // 8-wave tile (round 3): both k-steps' fragments are requested first and the stage's DMA pieces go out in two halves, in front of
-        // each k-step's MFMAs — a piece's issue takes the wave tens of cycles, six in a row at the top of the iteration idle the matrix
-        // pipe (SwiGLU 108 -> 104 us at 2048 rows, lm_head 121 -> 113 at 640, pair sums 24.2 -> 23.2 for mlp'; the 4-wave tile, two blocks
-        // per CU on 128 registers, spills with the second fragment set: 43 -> 74 us)
-        bf16x8 fa[2][4], fb[2][4];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int co = ((ks * 4 + kg) ^ sw) << 4;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                fa[ks][i] = *reinterpret_cast<const bf16x8*>(sA + offA + i * 2048 + co);
-                fb[ks][i] = *reinterpret_cast<const bf16x8*>(sB + offB + i * 2048 + co);
-            }
-        }
-        char* dA = smem + ((kt + NSTAGE - 1) % NSTAGE) * STAGE;
-        char* dB = dA + ASZ;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            if (pre) {
-                if (ks == 0) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) glds16(srcA[j] + (kt + NSTAGE - 1) * BKD, dA + (wave * 4 + j) * 1024);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < NB; ++j) glds16(srcB[j] + (kt + NSTAGE - 1) * BKD, dB + (wave * NB + j) * 1024);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    cur[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], fb[ks][j], cur[i][j], 0, 0, 0);
-        }
-        } else {
         if (pre) stage(kt + NSTAGE - 1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -201,32 +256,9 @@ __global__ __launch_bounds__(WN * 128) void gemm_dt_kernel(DtArgs a) {
                 for (int j = 0; j < 4; ++j)
                     cur[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], cur[i][j], 0, 0, 0);
         }
-        }
-        if (++in_seg == seg_kt || kt + 1 == nk) {     // end of a chain segment: fold it in, in order
+        if (++in_seg == seg_kt || kt + 1 == nk) {
             in_seg = 0;
-            if (MODE == 0) {
-                // the partial-sum family's order: (s0 + s1) + (s2 + s3) + ... — slices in adjacent pairs, pair sums in
-                // index order; an unpaired last slice is added on its own
-                const bool second = seg_idx & 1, last = kt + 1 == nk;
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (second) tot[i][j] += pairacc[i][j] + cur[i][j];
-                        else if (last) tot[i][j] += cur[i][j];
-                        else pairacc[i][j] = cur[i][j];
-                        cur[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
-                ++seg_idx;
-            } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    tot[i][j] += cur[i][j];
-                    cur[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
+            fold_segment(kt + 1 == nk);
         }
         // own share of stage kt+1 landed (later stages may stay in flight), then everybody's
         {
@@ -234,6 +266,7 @@ __global__ __launch_bounds__(WN * 128) void gemm_dt_kernel(DtArgs a) {
             wait_next(issued - (kt + 1));
         }
         __builtin_amdgcn_s_barrier();
+    }
     }
 
     // ---------------------------------------------------------------- epilogue
