@@ -280,7 +280,8 @@ def main() -> None:
         for kv in a.tune:
             k, v = kv.split("=")
             _lib.check(_lib.load().dh_set_tuning(int(k), int(v)))
-    cfg = Config.from_name(wl["model"], **{**GER_LORA, "dropout": 0.0})
+    # inference: dropout plays no role; the fine-tune runs at the reference's LoRA dropout (finetune/ger.py:401: 0.05), masks drawn in the kernel
+    cfg = Config.from_name(wl["model"], **{**GER_LORA, "dropout": 0.05 if wl.get("train") else 0.0})
     if "llama-3" in cfg.name.lower():
         cfg.block_size = 4096                      # inference/ger.py:189-190
     sd = synth_state_dict(cfg, seed=1337, device=dev, **SYNTH_KW)
@@ -560,7 +561,7 @@ def bench_finetune(a, wl, cfg, model, dev, rank: int, world: int, rehearsal: boo
             "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": wl["dtype"],
             "data": "synthetic", "device": device_identity(dev.index),
             "config": {"workload": wl["what"], "global_batch": GLOBAL, "micro_batches_per_rank_per_step": per_rank, "tokens": T,
-                       "micro_batches_per_packed_launch": PACK,
+                       "micro_batches_per_packed_launch": PACK, "lora_dropout": cfg.dropout,
                        "parallelism": f"data-parallel x{world}, flat LoRA-gradient bucket of {bucket.flat.numel()} fp32 elements",
                        **({"process_group": dist.get_backend()} if use_pg else {})},
             "roofline": {"bound": "mfma", "kernel": wl["kernel"], "achieved": achieved, "peak": wl["peak"], "unit": "TFLOP/s",

@@ -52,6 +52,7 @@ SIGNATURES = {
     "dh_finish_norm_bf16": (I, [P, I, I, I, I, I, P, F, P, P, P, P, F, P, P]),
     "dh_attn_decode_fused_bf16": (I, [P, I, I, I, I, I, P, F, I, I, P, P, P, P, P, P, P, I, I, I, I, P]),
     "dh_attn_prefill_bf16": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
+    "dh_dropout_bf16": (I, [P, P, P, I64, F, C.c_uint64, C.c_uint32, P, P]),
     "dh_swiglu_fwd_bf16": (I, [P, P, P, I64, P]),
     "dh_swiglu_bwd_bf16": (I, [P, P, P, P, I, I, P]),
     "dh_rmsnorm_bwd_bf16": (I, [P, P, P, P, P, I, I, F, P]),
@@ -111,7 +112,7 @@ def load() -> C.CDLL:
             raise DualHypHipError(f"libdualhyp_hip.so does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.dh_abi_version() != 4:
+    if lib.dh_abi_version() != 5:
         raise DualHypHipError("libdualhyp_hip.so ABI version mismatch")
     _lib = lib
     return lib

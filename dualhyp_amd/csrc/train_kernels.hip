@@ -273,6 +273,64 @@ extern "C" int dh_swiglu_bwd_bf16(const dh_bf16* dact, const dh_bf16* g, const d
     return 0;
 }
 
+// ---------------------------------------------------------------------------------- LoRA-branch dropout
+// ger/lora.py:96,165,391: nn.Dropout(p) on the input of lora_A only.  y = bf16(x * m), m = keep ? bf16(1 / (1 - p)) : 0 — what
+// torch computes for a bf16 tensor (mask.to(bf16) * scalar, then x * mask) — with the keep decisions drawn in the kernel from
+// Philox4x32-10 (key = seed, call id; counter = micro-step read from DEVICE memory, element block), so a captured hipGraph of
+// the micro-step draws fresh masks on every replay without a host-side launch parameter.  The mask is stored (bf16, one multiply
+// in the backward: d/dx = dy * m).  Not reproducible against the reference's CPU generator by construction.
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, bf16_t* __restrict__ mask,
+                                                      size_t n8, uint32_t thresh, bf16_t keep_scale, uint64_t seed, uint32_t call_id,
+                                                      const uint64_t* __restrict__ step_dev) {
+    const uint64_t step = step_dev ? *step_dev : 0;
+    const float ks = bf2f(keep_scale);
+    for (size_t c8 = blockIdx.x * (size_t)blockDim.x + threadIdx.x; c8 < n8; c8 += (size_t)gridDim.x * blockDim.x) {
+        // eight elements = two Philox calls of four 32-bit draws (counter: element block, half, micro-step)
+        const uint4 xv = reinterpret_cast<const uint4*>(x)[c8];
+        const bf16_t* xp = (const bf16_t*)&xv;
+        uint4 yo, mo;
+        bf16_t *yp = (bf16_t*)&yo, *mp = (bf16_t*)&mo;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint32_t ctr[4] = {(uint32_t)c8, (uint32_t)(c8 >> 32) * 2u + h, (uint32_t)step, (uint32_t)(step >> 32)};
+            philox4x32_10(ctr, (uint32_t)seed ^ (call_id * 0x9E3779B9u), (uint32_t)(seed >> 32) + call_id);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool keep = ctr[e] >= thresh;                  // P(keep) = 1 - p
+                mp[4 * h + e] = keep ? keep_scale : (bf16_t)0;
+                yp[4 * h + e] = keep ? f2bf(bf2f(xp[4 * h + e]) * ks) : (bf16_t)0;
+            }
+        }
+        reinterpret_cast<uint4*>(y)[c8] = yo;
+        reinterpret_cast<uint4*>(mask)[c8] = mo;
+    }
+}
+
+extern "C" int dh_dropout_bf16(const dh_bf16* x, dh_bf16* y, dh_bf16* mask, int64_t n, float p, uint64_t seed, uint32_t call_id,
+                               const uint64_t* step_dev, void* stream) {
+    DH_CHECK(x && y && mask && n % 8 == 0 && p >= 0.f && p < 1.f, "dh_dropout_bf16: bad argument (n=%lld, p=%g)", (long long)n, (double)p);
+    if (n <= 0) return 0;
+    const double t = (double)p * 4294967296.0;
+    const uint32_t thresh = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
+    const bf16_t ks = [](float v) { uint32_t u; memcpy(&u, &v, 4); u += 0x7fffu + ((u >> 16) & 1u); return (bf16_t)(u >> 16); }(1.0f / (1.0f - p));
+    const size_t n8 = (size_t)(n / 8);
+    const int blocks = (int)(n8 / 256 + 1 < 4096 ? n8 / 256 + 1 : 4096);
+    hipLaunchKernelGGL(dropout_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, mask, n8, thresh, ks, seed, call_id, step_dev);
+    DH_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int dh_swiglu_fwd_bf16(const dh_bf16* g, const dh_bf16* u, dh_bf16* act, int64_t n, void* stream) {
     DH_CHECK(g && u && act && n % 8 == 0, "dh_swiglu_fwd_bf16: bad argument");
     if (n <= 0) return 0;

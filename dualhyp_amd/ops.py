@@ -418,6 +418,16 @@ def vcache_to_plain(vt: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------ training backward
+def dropout(x: torch.Tensor, p: float, seed: int, call_id: int, step: Optional[torch.Tensor] = None):
+    """(bf16(x * m), m): LoRA-branch dropout with the mask drawn in the kernel (Philox keyed by seed / call_id, counted by the
+    device counter `step` — an int64 tensor of one element — and the element index); dh_dropout_bf16."""
+    x = _dev(x, name="x")
+    y, m = torch.empty_like(x), torch.empty_like(x)
+    check(_lib.load().dh_dropout_bf16(_p(x), _p(y), _p(m), x.numel(), float(p), int(seed) & (2 ** 64 - 1), int(call_id) & 0xffffffff,
+                                      _p(step) if step is not None else None, _stream()))
+    return y, m
+
+
 def swiglu_fwd(g: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
     k = _Keep()
     act = torch.empty_like(g)

@@ -106,12 +106,25 @@ class _Layer:
     __slots__ = ("x", "n1", "n1d", "xa", "q", "k", "v", "y", "lse", "xa2", "yd", "x1", "n2", "g", "u", "act", "mask1", "mask2")
 
 
-def _drop(x: torch.Tensor, p: float, training: bool):
-    """LoRA-branch dropout (ger/lora.py:96,165,391): mask scaled by 1/(1-p), result rounded to bf16."""
+def _drop(x: torch.Tensor, p: float, training: bool, model=None, call_id: int = 0):
+    """LoRA-branch dropout (ger/lora.py:96,165,391): mask scaled by 1/(1-p), result rounded to bf16.  The mask is drawn and
+    applied by ONE HIP kernel (ops.dropout, Philox keyed by the model's dropout seed and the call site, counted by a device-side
+    micro-step counter that `_DecoderFn.forward` bumps once per forward — so a captured hipGraph replays with fresh masks);
+    round 3 drew it with torch.rand and two ATen multiplies."""
     if not training or p <= 0.0:
         return x, None
-    mask = (torch.rand(x.shape, device=x.device) >= p).to(BF) * (1.0 / (1.0 - p))
-    return x * mask, mask
+    seed, step = _dropout_state(model, x.device)
+    return ops.dropout(x, p, seed, call_id, step)
+
+
+def _dropout_state(model, dev):
+    """(seed, device step counter) of a model's LoRA dropout: seeded from torch's generator at first use (torch.manual_seed makes
+    a run reproducible), the counter an int64 tensor on the device."""
+    st = getattr(model, "_dropout_rng", None)
+    if st is None or st[1].device != torch.device(dev):
+        st = (int(torch.initial_seed()) & (2 ** 63 - 1), torch.zeros(1, dtype=torch.int64, device=dev))
+        model._dropout_rng = st
+    return st
 
 
 class _DecoderFn(torch.autograd.Function):
@@ -141,6 +154,8 @@ class _DecoderFn(torch.autograd.Function):
         vt = torch.zeros((B, G, hs, s_max), dtype=BF, device=dev)
         p_drop, training = cfg.dropout, model.training
         saved: List[_Layer] = []
+        if training and p_drop > 0.0:
+            _dropout_state(model, dev)[1].add_(1)      # one micro-step: a torch op, so a hipGraph capture replays the bump too
         x = ops.embed(idx.reshape(-1), model.transformer.wte.weight.data)
         for blk in model.transformer.h:
             L = _Layer()
@@ -149,7 +164,7 @@ class _DecoderFn(torch.autograd.Function):
             L.n1 = ops.rmsnorm(x, blk.norm_1.weight.data, cfg.norm_eps, row_tail=tail)
             if qkv_m.lora_active:
                 A48, B16 = _lora_views(qkv_m, True)[:2]
-                L.n1d, L.mask1 = _drop(L.n1, p_drop, training)
+                L.n1d, L.mask1 = _drop(L.n1, p_drop, training, model, 2 * len(saved))
                 L.xa = ops.linear(L.n1d, A48)
                 qkv = ops.linear(L.n1, qkv_m.linear.weight.data, epilogue=ops.EPI_LORA, xa=L.xa, lora_b=B16,
                                  lora_scale=qkv_m.scaling, splits=qkv_m.splits)
@@ -163,7 +178,7 @@ class _DecoderFn(torch.autograd.Function):
             L.y = ops.attn_prefill(L.q, kc, vt, seq_slot, q_start, q_len, zeros, T, lse=L.lse)
             if proj_m.lora_active:
                 Ap, Bp = _lora_views(proj_m, False)[:2]
-                L.yd, L.mask2 = _drop(L.y, p_drop, training)
+                L.yd, L.mask2 = _drop(L.y, p_drop, training, model, 2 * len(saved) + 1)
                 L.xa2 = ops.linear(L.yd, Ap)
                 L.x1 = ops.linear(L.y, proj_m.linear.weight.data, epilogue=ops.EPI_LORA, xa=L.xa2, lora_b=Bp,
                                   lora_scale=proj_m.scaling, resid=x)

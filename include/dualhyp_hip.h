@@ -26,7 +26,7 @@ extern "C" {
 
 typedef uint16_t dh_bf16;
 
-#define DH_ABI_VERSION 4
+#define DH_ABI_VERSION 5
 
 int dh_abi_version(void);
 /* Kernel-variant selector for A/B measurements inside one process (bench.py --tune k=v); never needed in production,
@@ -205,6 +205,12 @@ int dh_attn_decode_fused_bf16(const float* qkv32, int n_part, int pairs, int n_s
  * finetune/ger.py:278-285 `fabric.backward(loss / accum)` for the frozen-base / LoRA-only case: the dX
  * GEMMs reuse dh_linear_bf16 on transposed copies of the frozen weights; these are the rest. */
 
+/* LoRA-branch dropout, ger/lora.py:96,165,391 (`nn.Dropout(p=lora_dropout)` in front of lora_A; finetune/ger.py:401 trains at
+ * 0.05): y = bf16(x * m), mask = m = keep ? bf16(1 / (1 - p)) : 0, keep drawn per element from Philox4x32-10 keyed by
+ * (seed, call_id) and counted by (*step_dev, element): `step_dev` is a DEVICE counter the caller bumps once per micro-step, so
+ * a captured hipGraph draws new masks on every replay (null = step 0).  n % 8 == 0.  ABI 5. */
+int dh_dropout_bf16(const dh_bf16* x, dh_bf16* y, dh_bf16* mask, int64_t n, float p, uint64_t seed, uint32_t call_id,
+                    const uint64_t* step_dev, void* stream);
 /* act = bf16(bf16(silu(g)) * u) from stored g, u (training forward keeps both; ger/model.py:315) */
 int dh_swiglu_fwd_bf16(const dh_bf16* g, const dh_bf16* u, dh_bf16* act, int64_t n, void* stream);
 /* dgu[rows, 2I] = [dact*u*silu'(g) | dact*silu(g)]   (backward of ger/model.py:315) */

@@ -636,3 +636,47 @@ def test_graph_cache_is_bounded_and_shares_one_pool():
     ids, labels = batch(192, 128)
     with pytest.raises(ValueError, match="n_targets"):
         step(ids, labels, 0.25, n_targets=200)
+
+
+def test_lora_dropout_kernel():
+    """dh_dropout_bf16 (ABI 5): the LoRA-branch dropout of ger/lora.py:96,165,391 with the mask drawn in the kernel.  The values are
+    torch's (x * (keep.to(bf16) * 1/(1-p)) in bf16), the keep rate is 1 - p, the draws are a pure function of (seed, call id,
+    device step counter, element) — and a captured hipGraph that bumps the counter draws a fresh mask on every replay."""
+    from dualhyp_amd import ops
+    p, n = 0.05, 1 << 20
+    x = torch.randn(n // 2048, 2048, device=DEV).bfloat16()
+    step = torch.zeros(1, dtype=torch.int64, device=DEV)
+    y, m = ops.dropout(x, p, seed=1337, call_id=3, step=step)
+    keep = m != 0
+    scale = torch.tensor(1.0 / (1.0 - p)).bfloat16()
+    assert torch.equal(m[keep], scale.to(DEV).expand_as(m[keep])) and float(m[~keep].abs().sum()) == 0
+    assert torch.equal(y, x * m)                                    # torch's bf16 multiply: the same rounding
+    rate = keep.float().mean().item()
+    assert abs(rate - (1 - p)) < 4 * (p * (1 - p) / n) ** 0.5 + 1e-4, rate
+    # no structure along rows / columns / 8-element groups (a broken counter would repeat or stripe)
+    assert abs(keep.float().mean(0) - (1 - p)).max().item() < 0.06 and abs(keep.float().mean(1) - (1 - p)).max().item() < 0.03
+    k8 = keep.view(-1, 8).float()
+    assert abs(torch.corrcoef(k8.T)[0, 1:]).max().item() < 0.01
+    # a pure function of its key and counter
+    y2, m2 = ops.dropout(x, p, seed=1337, call_id=3, step=step)
+    assert torch.equal(m2, m) and torch.equal(y2, y)
+    for kw in (dict(seed=1338, call_id=3), dict(seed=1337, call_id=4)):
+        _, mo = ops.dropout(x, p, step=step, **kw)
+        assert 0.85 < (mo == m).float().mean().item() < 0.95        # independent masks agree on (1-p)^2 + p^2 = 0.905
+    step.add_(1)
+    _, m3 = ops.dropout(x, p, seed=1337, call_id=3, step=step)
+    assert 0.85 < (m3 == m).float().mean().item() < 0.95
+    # under a hipGraph: the counter bump is captured, every replay draws anew
+    g, st = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        step.add_(1); ops.dropout(x, p, seed=1337, call_id=3, step=step)       # warm-up outside capture
+        torch.cuda.current_stream().synchronize()
+        with torch.cuda.graph(g, stream=st):
+            step.add_(1)
+            _, mg = ops.dropout(x, p, seed=1337, call_id=3, step=step)
+    g.replay(); torch.cuda.synchronize(); a = mg.clone()
+    g.replay(); torch.cuda.synchronize(); b = mg.clone()
+    assert 0.85 < (a == b).float().mean().item() < 0.95
+    # p = 0 keeps everything
+    y0, m0 = ops.dropout(x, 0.0, seed=1, call_id=0, step=step)
+    assert torch.equal(y0, x) and bool((m0 == 1).all())
