@@ -63,6 +63,67 @@ __device__ __forceinline__ void g256_tile_origin(const GemmArgs& a, const int bi
     n0 = (EPI == DH_EPI_SWIGLU) ? tn * 128 : tn * BT2;
 }
 
+// ---- v_dot2_f32_bf16 as the epilogues' bf16 arithmetic (round 4) ---------------------------------------------------------------
+// D = S0.lo * S1.lo + S0.hi * S1.hi + S2 on packed bf16 pairs, f32 result: one VALU issue slot (5.3 cycles for a wave alone on its
+// SIMD, tools/valu_issue.hip — the price of a v_mul_f32), and what the eager-bf16 reference does between two rounding points is
+// exactly such a term:
+//   * a PRODUCT of two bf16 values: (x_e, x_e+1) . (c_e, 0) = x_e c_e — exact in f32 like v_mul_f32 on the expanded operands, with
+//     no expansion of x (the v_cvt_pk_bf16_f32 result is the operand) and the negation of rotate-half as a free source modifier;
+//   * the SUM of two bf16 values that sit in one register, (a, b) . (1, 1): v_cvt_pk_bf16_f32(acc, lora) IS (bf16(acc), bf16(lora)),
+//     so "round both, add" is two instructions.  The dot's internal sum is not the IEEE f32 sum when the exponents are > 16 apart,
+//     but ROUNDED TO BF16 (the next thing that happens to it at every use here) it is: tools/dot2_probe.hip, 2^31 operand pairs
+//     incl. every bf16 pattern against near and far exponents: 0 differences (profiles/r04_dot2_probe.txt).
+// Two consequences of the zero-padded second product: a non-finite x_e+1 turns x_e's product into NaN (0 * inf) — a row with an
+// inf / NaN in q or k is lost in the attention anyway — and the sign of an exactly-zero product is +0 (numerically equal).
+// HAZARD: on gfx90a+ a DOT instruction's result needs 3 wait states before another VALU instruction reads it (4 before one
+// overwrites it; LLVM GCNHazardRecognizer DotWriteDifferentVALURead / ...VALUWrite).  The compiler pads this only for instructions it
+// knows, and its own selection of the builtin is the accumulate form v_dot2c (D += ., i.e. a v_mov 0 per use), so the dots are
+// written as asm BLOCKS whose instruction order keeps every dot result >= 3 instructions away from its reader; each block ends
+// >= 4 instructions behind its last dot, and only v_cvt_pk results leave a block.  (First version: single-instruction asms, every
+// rotated value wrong on the GPU — v_cvt_pk read its dot operands one instruction behind them.)  Blocks only ever read VALU
+// results: MFMA results go through a compiler-visible v_cvt_pk first.
+#define DH_ONES_BF16X2 0x3f803f80u
+// y0 = cvt_pk(lo + hi of p0, of p1), y1 = cvt_pk(.. p2, .. p3), y2, y3 likewise from p4..p7: eight "round both, add", four packs
+__device__ __forceinline__ void dot2_sum8_pack(uint32_t (&p)[8], uint32_t& y0, uint32_t& y1, uint32_t& y2, uint32_t& y3) {
+    asm("v_dot2_f32_bf16 %0, %0, %12, 0\n\tv_dot2_f32_bf16 %1, %1, %12, 0\n\tv_dot2_f32_bf16 %2, %2, %12, 0\n\tv_dot2_f32_bf16 %3, %3, %12, 0\n\t"
+        "v_dot2_f32_bf16 %4, %4, %12, 0\n\tv_dot2_f32_bf16 %5, %5, %12, 0\n\tv_dot2_f32_bf16 %6, %6, %12, 0\n\tv_dot2_f32_bf16 %7, %7, %12, 0\n\t"
+        "v_cvt_pk_bf16_f32 %8, %0, %1\n\tv_cvt_pk_bf16_f32 %9, %2, %3\n\tv_cvt_pk_bf16_f32 %10, %4, %5\n\tv_cvt_pk_bf16_f32 %11, %6, %7"
+        : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]), "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3)
+        : "s"(DH_ONES_BF16X2));
+}
+// One half of the rotation of a 16-column tile pair (4 outputs per lane): out_e = bf16(a_e ca_e) + bf16(+-b_e cb_e), e = 0..3, with
+// a = (ax: e 0,1 | ay: e 2,3), b likewise, and per e the masked table operand (c, 0) for even e / (0, c) for odd e.  NEG: the second
+// product negated (rotate-half's -x2 sin).  8 products, 4 cvt_pk (= both roundings), 4 sums, 2 packs; the s_nop keeps the last sums
+// 3 wait states from their pack.
+template <bool NEG>
+__device__ __forceinline__ uint2 rope_half(uint32_t ax, uint32_t ay, uint32_t bx, uint32_t by, const uint32_t (&ca)[4], const uint32_t (&cb)[4]) {
+    uint32_t t0, t1, t2, t3, t4, t5, t6, t7, o0, o1;
+    if constexpr (NEG) {
+        asm("v_dot2_f32_bf16 %0, %10, %14, 0\n\tv_dot2_f32_bf16 %1, %12, %18, 0 neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"
+            "v_dot2_f32_bf16 %2, %10, %15, 0\n\tv_dot2_f32_bf16 %3, %12, %19, 0 neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"
+            "v_dot2_f32_bf16 %4, %11, %16, 0\n\tv_dot2_f32_bf16 %5, %13, %20, 0 neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"
+            "v_dot2_f32_bf16 %6, %11, %17, 0\n\tv_dot2_f32_bf16 %7, %13, %21, 0 neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"
+            "v_cvt_pk_bf16_f32 %0, %0, %1\n\tv_cvt_pk_bf16_f32 %2, %2, %3\n\tv_cvt_pk_bf16_f32 %4, %4, %5\n\tv_cvt_pk_bf16_f32 %6, %6, %7\n\t"
+            "v_dot2_f32_bf16 %1, %0, %22, 0\n\tv_dot2_f32_bf16 %3, %2, %22, 0\n\tv_dot2_f32_bf16 %5, %4, %22, 0\n\tv_dot2_f32_bf16 %7, %6, %22, 0\n\t"
+            "s_nop 1\n\tv_cvt_pk_bf16_f32 %8, %1, %3\n\tv_cvt_pk_bf16_f32 %9, %5, %7"
+            : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "=&v"(o0), "=&v"(o1)
+            : "v"(ax), "v"(ay), "v"(bx), "v"(by), "v"(ca[0]), "v"(ca[1]), "v"(ca[2]), "v"(ca[3]), "v"(cb[0]), "v"(cb[1]), "v"(cb[2]), "v"(cb[3]),
+              "s"(DH_ONES_BF16X2));
+    } else {
+        asm("v_dot2_f32_bf16 %0, %10, %14, 0\n\tv_dot2_f32_bf16 %1, %12, %18, 0\n\t"
+            "v_dot2_f32_bf16 %2, %10, %15, 0\n\tv_dot2_f32_bf16 %3, %12, %19, 0\n\t"
+            "v_dot2_f32_bf16 %4, %11, %16, 0\n\tv_dot2_f32_bf16 %5, %13, %20, 0\n\t"
+            "v_dot2_f32_bf16 %6, %11, %17, 0\n\tv_dot2_f32_bf16 %7, %13, %21, 0\n\t"
+            "v_cvt_pk_bf16_f32 %0, %0, %1\n\tv_cvt_pk_bf16_f32 %2, %2, %3\n\tv_cvt_pk_bf16_f32 %4, %4, %5\n\tv_cvt_pk_bf16_f32 %6, %6, %7\n\t"
+            "v_dot2_f32_bf16 %1, %0, %22, 0\n\tv_dot2_f32_bf16 %3, %2, %22, 0\n\tv_dot2_f32_bf16 %5, %4, %22, 0\n\tv_dot2_f32_bf16 %7, %6, %22, 0\n\t"
+            "s_nop 1\n\tv_cvt_pk_bf16_f32 %8, %1, %3\n\tv_cvt_pk_bf16_f32 %9, %5, %7"
+            : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "=&v"(o0), "=&v"(o1)
+            : "v"(ax), "v"(ay), "v"(bx), "v"(by), "v"(ca[0]), "v"(ca[1]), "v"(ca[2]), "v"(ca[3]), "v"(cb[0]), "v"(cb[1]), "v"(cb[2]), "v"(cb[3]),
+              "s"(DH_ONES_BF16X2));
+    }
+    return make_uint2(o0, o1);
+}
+
 // The epilogue of a wave that owns 128 (n) x 16 MJ (m) of the block tile: acc[i][j] is the 16 x 16 tile of column tile i, row
 // strip j.  MJ = 4: the 8-wave kernel (waves 2 x 4), MJ = 8: the 4-wave kernel (waves 2 x 2).
 // FULL: the block tile lies inside the matrix — every bound below is then known at compile time, the epilogue has no exec-mask
@@ -330,13 +391,52 @@ __device__ __forceinline__ void g256_epilogue(const GemmArgs& a, f32x4 (&acc)[8]
         };
 #pragma unroll
         for (int ip = 0; ip < NT / 2; ++ip) {
-            uint2 ta = tile_value(2 * ip), tb = tile_value(2 * ip + 1);
+            uint2 ta, tb;
+#ifndef DH_W4_OLD_EPI
+            // round 4, the 4-wave kernel's full tiles: "round both, add" of the LoRA finish as v_cvt_pk + v_dot2 (see dot2_sum8_pack)
+            constexpr bool DOT = FULL && MJ == 8 && ((EPI == DH_EPI_LORA && XS) || (EPI == DH_EPI_PLAIN && RESID));   // (LoRA with xa from memory: 8 spilled registers)
+#else
+            constexpr bool DOT = false;
+#endif
+            if constexpr (DOT && EPI == DH_EPI_LORA) {
+                if (a.lora_scale == 1.f) {                       // wave-uniform (alpha == r in both reference harnesses)
+                    const f32x4 la = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lbv[LORA ? 2 * ip : 0], xfv[LORA ? ip : 0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    const f32x4 lb = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lbv[LORA ? 2 * ip + 1 : 0], xfv[LORA ? ip : 0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    uint32_t pk[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        pk[e] = pack2bf(acc[2 * ip][j][e], la[e]);
+                        pk[4 + e] = pack2bf(acc[2 * ip + 1][j][e], lb[e]);
+                    }
+                    dot2_sum8_pack(pk, ta.x, ta.y, tb.x, tb.y);
+                } else {
+                    ta = tile_value(2 * ip);
+                    tb = tile_value(2 * ip + 1);
+                }
+            } else if constexpr (DOT) {                          // plain: one v_cvt_pk per pair of values
+                ta = make_uint2(pack2bf(acc[2 * ip][j][0], acc[2 * ip][j][1]), pack2bf(acc[2 * ip][j][2], acc[2 * ip][j][3]));
+                tb = make_uint2(pack2bf(acc[2 * ip + 1][j][0], acc[2 * ip + 1][j][1]), pack2bf(acc[2 * ip + 1][j][2], acc[2 * ip + 1][j][3]));
+            } else {
+                ta = tile_value(2 * ip);
+                tb = tile_value(2 * ip + 1);
+            }
             const int nb = nw0 + ip * 32;                        // first column of the pair (wave-uniform)
             if (FULL || nb + 32 <= a.N) {
                 const auto rx = __builtin_amdgcn_permlane16_swap(ta.x, tb.x, false, false);
                 const auto ry = __builtin_amdgcn_permlane16_swap(ta.y, tb.y, false, false);
                 uint4 out = make_uint4(rx[0], ry[0], rx[1], ry[1]);
-                if (RESID) {
+                if constexpr (RESID && DOT) {
+                    // bf16(resid + y) on 8 values: (y, r) pairs by v_perm, then the same "add the two halves" block
+                    const uint4 rr = rrv[RESID ? ip : 0];
+                    const uint32_t yv[4] = {out.x, out.y, out.z, out.w}, rv[4] = {rr.x, rr.y, rr.z, rr.w};
+                    uint32_t pk[8];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        pk[2 * q] = __builtin_amdgcn_perm(rv[q], yv[q], 0x05040100u);       // (y lo, r lo)
+                        pk[2 * q + 1] = __builtin_amdgcn_perm(rv[q], yv[q], 0x07060302u);   // (y hi, r hi)
+                    }
+                    dot2_sum8_pack(pk, out.x, out.y, out.z, out.w);
+                } else if (RESID) {
                     const uint4 rr = rrv[RESID ? ip : 0];
                     auto add2 = [](uint32_t y2, uint32_t r2) __attribute__((always_inline)) -> uint32_t {
                         return pack2bf(bf2f((bf16_t)(r2 & 0xffffu)) + bf2f((bf16_t)(y2 & 0xffffu)),
@@ -360,67 +460,6 @@ __device__ __forceinline__ void g256_epilogue(const GemmArgs& a, f32x4 (&acc)[8]
             }
         }
     });
-}
-
-// ---- v_dot2_f32_bf16 as the epilogues' bf16 arithmetic (round 4) ---------------------------------------------------------------
-// D = S0.lo * S1.lo + S0.hi * S1.hi + S2 on packed bf16 pairs, f32 result: one VALU issue slot (5.3 cycles for a wave alone on its
-// SIMD, tools/valu_issue.hip — the price of a v_mul_f32), and what the eager-bf16 reference does between two rounding points is
-// exactly such a term:
-//   * a PRODUCT of two bf16 values: (x_e, x_e+1) . (c_e, 0) = x_e c_e — exact in f32 like v_mul_f32 on the expanded operands, with
-//     no expansion of x (the v_cvt_pk_bf16_f32 result is the operand) and the negation of rotate-half as a free source modifier;
-//   * the SUM of two bf16 values that sit in one register, (a, b) . (1, 1): v_cvt_pk_bf16_f32(acc, lora) IS (bf16(acc), bf16(lora)),
-//     so "round both, add" is two instructions.  The dot's internal sum is not the IEEE f32 sum when the exponents are > 16 apart,
-//     but ROUNDED TO BF16 (the next thing that happens to it at every use here) it is: tools/dot2_probe.hip, 2^31 operand pairs
-//     incl. every bf16 pattern against near and far exponents: 0 differences (profiles/r04_dot2_probe.txt).
-// Two consequences of the zero-padded second product: a non-finite x_e+1 turns x_e's product into NaN (0 * inf) — a row with an
-// inf / NaN in q or k is lost in the attention anyway — and the sign of an exactly-zero product is +0 (numerically equal).
-// HAZARD: on gfx90a+ a DOT instruction's result needs 3 wait states before another VALU instruction reads it (4 before one
-// overwrites it; LLVM GCNHazardRecognizer DotWriteDifferentVALURead / ...VALUWrite).  The compiler pads this only for instructions it
-// knows, and its own selection of the builtin is the accumulate form v_dot2c (D += ., i.e. a v_mov 0 per use), so the dots are
-// written as asm BLOCKS whose instruction order keeps every dot result >= 3 instructions away from its reader; each block ends
-// >= 4 instructions behind its last dot, and only v_cvt_pk results leave a block.  (First version: single-instruction asms, every
-// rotated value wrong on the GPU — v_cvt_pk read its dot operands one instruction behind them.)  Blocks only ever read VALU
-// results: MFMA results go through a compiler-visible v_cvt_pk first.
-#define DH_ONES_BF16X2 0x3f803f80u
-// y0 = cvt_pk(lo + hi of p0, of p1), y1 = cvt_pk(.. p2, .. p3), y2, y3 likewise from p4..p7: eight "round both, add", four packs
-__device__ __forceinline__ void dot2_sum8_pack(uint32_t (&p)[8], uint32_t& y0, uint32_t& y1, uint32_t& y2, uint32_t& y3) {
-    asm("v_dot2_f32_bf16 %0, %0, %12, 0\n\tv_dot2_f32_bf16 %1, %1, %12, 0\n\tv_dot2_f32_bf16 %2, %2, %12, 0\n\tv_dot2_f32_bf16 %3, %3, %12, 0\n\t"
-        "v_dot2_f32_bf16 %4, %4, %12, 0\n\tv_dot2_f32_bf16 %5, %5, %12, 0\n\tv_dot2_f32_bf16 %6, %6, %12, 0\n\tv_dot2_f32_bf16 %7, %7, %12, 0\n\t"
-        "v_cvt_pk_bf16_f32 %8, %0, %1\n\tv_cvt_pk_bf16_f32 %9, %2, %3\n\tv_cvt_pk_bf16_f32 %10, %4, %5\n\tv_cvt_pk_bf16_f32 %11, %6, %7"
-        : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]), "+v"(p[4]), "+v"(p[5]), "+v"(p[6]), "+v"(p[7]), "=&v"(y0), "=&v"(y1), "=&v"(y2), "=&v"(y3)
-        : "s"(DH_ONES_BF16X2));
-}
-// One half of the rotation of a 16-column tile pair (4 outputs per lane): out_e = bf16(a_e ca_e) + bf16(+-b_e cb_e), e = 0..3, with
-// a = (ax: e 0,1 | ay: e 2,3), b likewise, and per e the masked table operand (c, 0) for even e / (0, c) for odd e.  NEG: the second
-// product negated (rotate-half's -x2 sin).  8 products, 4 cvt_pk (= both roundings), 4 sums, 2 packs; the s_nop keeps the last sums
-// 3 wait states from their pack.
-template <bool NEG>
-__device__ __forceinline__ uint2 rope_half(uint32_t ax, uint32_t ay, uint32_t bx, uint32_t by, const uint32_t (&ca)[4], const uint32_t (&cb)[4]) {
-    uint32_t t0, t1, t2, t3, t4, t5, t6, t7, o0, o1;
-    if constexpr (NEG) {
-        asm("v_dot2_f32_bf16 %0, %10, %14, 0\n\tv_dot2_f32_bf16 %1, %12, %18, 0 neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"
-            "v_dot2_f32_bf16 %2, %10, %15, 0\n\tv_dot2_f32_bf16 %3, %12, %19, 0 neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"
-            "v_dot2_f32_bf16 %4, %11, %16, 0\n\tv_dot2_f32_bf16 %5, %13, %20, 0 neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"
-            "v_dot2_f32_bf16 %6, %11, %17, 0\n\tv_dot2_f32_bf16 %7, %13, %21, 0 neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"
-            "v_cvt_pk_bf16_f32 %0, %0, %1\n\tv_cvt_pk_bf16_f32 %2, %2, %3\n\tv_cvt_pk_bf16_f32 %4, %4, %5\n\tv_cvt_pk_bf16_f32 %6, %6, %7\n\t"
-            "v_dot2_f32_bf16 %1, %0, %22, 0\n\tv_dot2_f32_bf16 %3, %2, %22, 0\n\tv_dot2_f32_bf16 %5, %4, %22, 0\n\tv_dot2_f32_bf16 %7, %6, %22, 0\n\t"
-            "s_nop 1\n\tv_cvt_pk_bf16_f32 %8, %1, %3\n\tv_cvt_pk_bf16_f32 %9, %5, %7"
-            : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "=&v"(o0), "=&v"(o1)
-            : "v"(ax), "v"(ay), "v"(bx), "v"(by), "v"(ca[0]), "v"(ca[1]), "v"(ca[2]), "v"(ca[3]), "v"(cb[0]), "v"(cb[1]), "v"(cb[2]), "v"(cb[3]),
-              "s"(DH_ONES_BF16X2));
-    } else {
-        asm("v_dot2_f32_bf16 %0, %10, %14, 0\n\tv_dot2_f32_bf16 %1, %12, %18, 0\n\t"
-            "v_dot2_f32_bf16 %2, %10, %15, 0\n\tv_dot2_f32_bf16 %3, %12, %19, 0\n\t"
-            "v_dot2_f32_bf16 %4, %11, %16, 0\n\tv_dot2_f32_bf16 %5, %13, %20, 0\n\t"
-            "v_dot2_f32_bf16 %6, %11, %17, 0\n\tv_dot2_f32_bf16 %7, %13, %21, 0\n\t"
-            "v_cvt_pk_bf16_f32 %0, %0, %1\n\tv_cvt_pk_bf16_f32 %2, %2, %3\n\tv_cvt_pk_bf16_f32 %4, %4, %5\n\tv_cvt_pk_bf16_f32 %6, %6, %7\n\t"
-            "v_dot2_f32_bf16 %1, %0, %22, 0\n\tv_dot2_f32_bf16 %3, %2, %22, 0\n\tv_dot2_f32_bf16 %5, %4, %22, 0\n\tv_dot2_f32_bf16 %7, %6, %22, 0\n\t"
-            "s_nop 1\n\tv_cvt_pk_bf16_f32 %8, %1, %3\n\tv_cvt_pk_bf16_f32 %9, %5, %7"
-            : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7), "=&v"(o0), "=&v"(o1)
-            : "v"(ax), "v"(ay), "v"(bx), "v"(by), "v"(ca[0]), "v"(ca[1]), "v"(ca[2]), "v"(ca[3]), "v"(cb[0]), "v"(cb[1]), "v"(cb[2]), "v"(cb[3]),
-              "s"(DH_ONES_BF16X2));
-    }
-    return make_uint2(o0, o1);
 }
 
 // The fused-QKV epilogue of the 4-wave kernel for a FULL tile with the in-GEMM LoRA down-projection (the prefill of both model
