@@ -465,8 +465,11 @@ def main() -> None:
         for k in (0, len(timed_prompts) - 1):
             alone = generate_batch(model, [timed_prompts[k]], NEW_TOKENS, **gen_kw)[0]
             same.append(bool(torch.equal(alone.cpu(), all_out[k].cpu())))
-        result["parity"] = {"oracle": None, "note": "oracle parity of this configuration is asserted in tests/ (test_hip_fp8.py, "
-                            "test_hip_model.py::test_llama3_8b_shape_vs_reference); in the run: timed rows against the same prompts decoded alone",
+        result["parity"] = {"oracle": None, "note": "oracle / reference parity of this configuration at its real prompt length is asserted in tests/: "
+                            "test_hip_model.py::test_llama3_8b_shape_vs_reference[llama3_shape_1536] (bf16) and "
+                            "test_hip_fp8.py::test_fp8_llama3_shape_vs_reference[llama3_shape_1536] (fp8) — tests/golden/llama3_shape_1536: the reference's own "
+                            "logits, top-8 and greedy ids at T = 1536 + 16 decode steps, two layers of this shape — and the hs-128 attention kernels against the "
+                            "oracle's SDPA up to 1700 keys (test_hip_ops.py, \"long\" cases); in the run: timed rows against the same prompts decoded alone",
                             "timed_rows_equal_alone_runs": same, "pass": all(same)}
     elif rank == 0 and world == 1 and not a.no_cpu_baseline:
         # the oracle decodes the first utterances of the timed region; its ids and logits are the checker for what the

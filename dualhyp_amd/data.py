@@ -150,6 +150,17 @@ def collate(samples: Sequence[Dict[str, Any]]) -> Dict[str, Any]:
     return out
 
 
+def feature_key(item: Dict[str, Any], stream: str, n_variants: int) -> str:
+    """File stem of an utterance variant's encoder features (RelPrompt; `--enc_features_dir`): the Uid when the JSON holds ONE
+    item for it, else Uid + a stable hash of that item's corruption record of `stream` ("Audio_Corruption" / "Visual_Corruption"),
+    so features and mask targets always describe the same corruption."""
+    if n_variants <= 1:
+        return str(item["Uid"])
+    import hashlib
+    rec = json.dumps(item.get(stream, {}), sort_keys=True)
+    return f"{item['Uid']}.{hashlib.sha1(rec.encode()).hexdigest()[:10]}"
+
+
 class HypothesesDataset:
     """JSON -> examples.  Items sharing a `Uid` are alternative corruptions of one utterance; the dual
     formats draw the ASR and the VSR item independently with `random.choices(k=2)`
@@ -203,5 +214,7 @@ class HypothesesDataset:
             ex["audio_mask_targets"] = torch.tensor([cls.get(l, 2) for l in al], dtype=torch.int64)
             ex["visual_mask_targets"] = torch.tensor([cls.get(l, 2) for l in vl], dtype=torch.int64)
             if self.enc_features is not None:
+                # the features must describe the SAME corruption as the mask targets built from s1 / s2 above: a Uid with several
+                # noise variants is served per variant (feature_key below), never by the Uid alone
                 ex["audio_enc_features"], ex["visual_enc_features"] = self.enc_features(s1, s2)
         return ex

@@ -396,16 +396,24 @@ def main(argv: Optional[Sequence[str]] = None) -> Dict[str, float]:
     model = model.to(device=dev, dtype=torch.bfloat16)
     fmt = args.prompts_format if (args.dual_hypotheses or rel) else "GER"
     enc_features = None
+    _variants: dict = {}          # Uid -> its items, filled by dataset() below
     if rel and args.enc_features_dir:
         def enc_features(s1, s2, _d=Path(args.enc_features_dir)):
-            f = torch.load(_d / f"{s1['Uid']}.pt", map_location="cpu")
-            return f["audio"].float(), f["visual"].float()
+            # <dir>/<Uid>.pt = {'audio', 'visual'} when the Uid has one variant; with several, the audio features of s1's corruption
+            # and the visual features of s2's come from <Uid>.<hash of that corruption record>.pt (data.feature_key)
+            from .data import feature_key
+            n_var = len(_variants.get(s1["Uid"], (s1,)))
+            fa = torch.load(_d / f"{feature_key(s1, 'Audio_Corruption', n_var)}.pt", map_location="cpu")
+            fv = fa if n_var <= 1 else torch.load(_d / f"{feature_key(s2, 'Visual_Corruption', n_var)}.pt", map_location="cpu")
+            return fa["audio"].float(), fv["visual"].float()
 
     def dataset(path, seed):
         items = []
         for one in ([path] if isinstance(path, str) else path):
             with open(one, encoding="utf-8") as f:
                 items += json.load(f)
+        for it in items:
+            _variants.setdefault(it["Uid"], []).append(it)
         return HypothesesDataset(items, tokenizer, prompts_format=fmt, nhyps_key=args.nhyps_key, max_nhyps=args.max_nhyps,
                                  max_input_length=max_input_length, language=args.language, seed=seed,
                                  mask_threshold=args.mask_threshold, time_window=args.time_window, enc_features=enc_features)

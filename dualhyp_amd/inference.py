@@ -156,14 +156,21 @@ def result(adapter_path: str, model, tokenizer, args, rank: int = 0, world: int 
     # (inference/relprompt.py:113-153); without features the ground-truth chunk labels of the corruption records are used
     feats_dir = getattr(args, "enc_features_dir", None) if fmt == "RelPrompt" else None
     enc_features = None
+    _variants: dict = {}          # Uid -> its items (filled from the dataset below; read when a feature file is looked up)
     if feats_dir:
         def enc_features(s1, s2, _d=Path(feats_dir)):
-            f = torch.load(_d / f"{s1['Uid']}.pt", map_location="cpu")
-            return f["audio"].float(), f["visual"].float()
+            # <dir>/<Uid>.pt = {'audio', 'visual'} when the Uid has one variant; with several, the audio features of s1's corruption
+            # and the visual features of s2's come from <Uid>.<hash of that corruption record>.pt (data.feature_key)
+            from .data import feature_key
+            n_var = len(_variants.get(s1["Uid"], (s1,)))
+            fa = torch.load(_d / f"{feature_key(s1, 'Audio_Corruption', n_var)}.pt", map_location="cpu")
+            fv = fa if n_var <= 1 else torch.load(_d / f"{feature_key(s2, 'Visual_Corruption', n_var)}.pt", map_location="cpu")
+            return fa["audio"].float(), fv["visual"].float()
     ds = HypothesesDataset(args.test_path, tokenizer, prompts_format=fmt if (args.dual_hypotheses or fmt == "RelPrompt") else "GER",
                            nhyps_key=args.nhyps_key, max_nhyps=args.max_nhyps, language=args.language, seed=args.seed,
                            mask_threshold=getattr(args, "mask_threshold", None), time_window=getattr(args, "time_window", 0.4),
                            enc_features=enc_features, leave_masks=bool(feats_dir))
+    _variants.update(ds.uid2sample)
     examples = [ds[i] for i in range(len(ds))]
     mask_stats = None
     if feats_dir:
@@ -179,6 +186,22 @@ def result(adapter_path: str, model, tokenizer, args, rank: int = 0, world: int 
                 hit[name][1] += n
         mask_stats = {f"{k}_mask_accuracy": h[0] / max(h[1], 1) for k, h in hit.items()}
     eos = tokenizer.eos_token_id
+
+    # --decode_batch is a throughput knob tuned on TinyLlama (2 x 22.5 KB of KV per position); the KV cache is allocated for
+    # decode_batch x (longest prompt + max_new_tokens) positions, so bound it by what the device has free (Llama-3-8B: 131 KB per
+    # position — 640 x 1700 positions would be 140 GB)
+    if torch.cuda.is_available() and model.transformer.wte.weight.is_cuda:
+        c_ = model.config
+        kv_per_pos = c_.n_layer * 2 * c_.n_query_groups * c_.head_size * 2
+        longest = max((int(e["input_ids_no_response"].numel()) for e in examples), default=1) + args.max_new_tokens
+        free, _total = torch.cuda.mem_get_info(model.transformer.wte.weight.device)
+        fit = int(0.8 * free // max(kv_per_pos * longest, 1))
+        if fit < 1:
+            raise RuntimeError(f"not enough device memory for one sequence of {longest} positions ({kv_per_pos * longest / 2**30:.1f} GiB of KV cache)")
+        if fit < args.decode_batch:
+            print(f"[dualhyp_amd] --decode_batch {args.decode_batch} -> {fit}: {kv_per_pos * longest / 2**20:.0f} MiB of KV cache per sequence, "
+                  f"{free / 2**30:.0f} GiB free")
+            args.decode_batch = fit
 
     def gen(prompts):
         dev = model.transformer.wte.weight.device

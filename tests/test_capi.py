@@ -40,3 +40,50 @@ def test_product_never_imports_oracle():
     for p in (REPO / "dualhyp_amd").rglob("*.py"):
         src = p.read_text()
         assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S).replace("# oracle", ""), p
+
+
+_FAKE_S = """_ZN4testgemm_nt256w4_kernelEv:
+.LBB0_1:
+	;;#ASMSTART
+	v_mfma_f32_16x16x32_bf16 a[0:3], v[10:13], v[20:23], a[0:3]
+	;;#ASMEND
+	;;#ASMSTART
+	v_mfma_f32_16x16x32_bf16 a[4:7], v[10:13], v[24:27], a[4:7]
+	;;#ASMEND
+%s
+	;;#ASMSTART
+	v_mfma_f32_16x16x32_bf16 a[0:3], v[14:17], v[20:23], a[0:3]
+	;;#ASMEND
+	;;#ASMSTART
+	s_nop 15
+	s_nop 15
+	;;#ASMEND
+	v_accvgpr_read_b32 v1, a0
+	s_endpgm
+"""
+
+
+def test_asm_mfma_hazard_checker(tmp_path):
+    """tools/check_asm_mfma.py: the 4-wave GEMM's MFMAs are asm, invisible to the compiler's hazard recognizer; the
+    checker must flag a compiler-generated accumulator read right behind the MFMA that produces it (the round-3 bug class) and a
+    write right in front of the MFMA that consumes it, and accept reads behind the fence."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_asm_mfma", REPO / "tools" / "check_asm_mfma.py")
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    for body, want in (("\tv_add_u32_e32 v2, v3, v4", 0), ("\tv_accvgpr_read_b32 v1, a5", 1), ("\tv_accvgpr_write_b32 a1, v9", 1),
+                       ("\tv_accvgpr_mov_b32 a2, a6", 2)):
+        f = tmp_path / "k.s"
+        f.write_text(_FAKE_S % body)
+        assert chk.main(str(f)) == (1 if want else 0), body
+
+
+@pytest.mark.skipif(not __import__("os").environ.get("DUALHYP_SLOW"), reason="compiles gemm256.hip with --save-temps (~2 min); DUALHYP_SLOW=1")
+def test_gemm256_has_no_asm_mfma_hazards(tmp_path):
+    import subprocess
+    import __graft_entry__ as ge
+    subprocess.run([ge.HIPCC, *ge.FLAGS, "-save-temps", "-c", str(ge.CSRC / "gemm256.hip"), "-o", str(tmp_path / "g.o")], cwd=tmp_path, check=True,
+                   capture_output=True)
+    s = next(tmp_path.glob("*gfx950.s"))
+    out = subprocess.run([__import__("sys").executable, str(REPO / "tools" / "check_asm_mfma.py"), str(s)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-3000:]

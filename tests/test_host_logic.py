@@ -361,3 +361,14 @@ def test_data_parallel_fit_validates_sharded_and_writes_one_checkpoint(tmp_path)
         assert torch.allclose(la[k], lora_single[k], rtol=1e-5, atol=1e-6), k   # global batch 4 = 2 ranks x 2 = 1 rank x 4
         assert torch.equal(final[k], la[k]), k
     assert lines_b == [] or all("val loss" in l for l in lines_b)
+
+
+def test_feature_files_are_keyed_by_the_corruption_variant():
+    """RelPrompt encoder features were looked up by Uid alone while the mask targets come from the CHOSEN variants'
+    corruption records.  One item per Uid keeps <Uid>.pt; several get one file per corruption record."""
+    a, b = sample("u1", snr=-5), sample("u1", snr=5)
+    b["Audio_Corruption"] = dict(b["Audio_Corruption"], start_fr=100)
+    assert D.feature_key(a, "Audio_Corruption", 1) == "u1"
+    ka, kb = D.feature_key(a, "Audio_Corruption", 2), D.feature_key(b, "Audio_Corruption", 2)
+    assert ka != kb and ka.startswith("u1.") and kb.startswith("u1.") and ka == D.feature_key(dict(a), "Audio_Corruption", 2)
+    assert D.feature_key(a, "Visual_Corruption", 2) == D.feature_key(b, "Visual_Corruption", 2)    # same visual record -> same file
