@@ -18,6 +18,8 @@ ALG = {   # kernel template args -> (what, algorithmic bytes per launch)
     "<1, false": ("qkv + LoRA", 2 * (M * d + 2560 * d + M * 2560 + M * 48 + 2560 * 16)),
     "<1, true": ("attn proj + LoRA + residual", 2 * (M * d + d * d + 2 * M * d + M * 16 + d * 16)),
     "<2, false": ("fc_1/fc_2 SwiGLU", 2 * (M * d + 2 * I * d + M * I)),
+    # round 4's bench launch: the fused QKV GEMM (EPI 4) reads x, W, A, B, writes q / k / v (2560 columns per token) once
+    "<4, false": ("qkv + LoRA + rope + cache append", 2 * (M * d + 2560 * d + 48 * d + 2560 * 16 + M * 2560)),
 }
 
 
