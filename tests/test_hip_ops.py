@@ -291,6 +291,33 @@ def test_qkv_gemm_with_rope_and_cache_epilogue(dev, hs, n_head, n_groups, lora):
     finally:
         lib.dh_set_tuning(1, 5)
         lib.dh_set_tuning(22, 1)
+    if lora:
+        # round 4: the ABI-4 entry point with the LoRA down-projection inside the K loop runs the rebuilt epilogue (v_dot2 arithmetic,
+        # one loop over the row strips, V^T through LDS as 16-byte stores where a strip is 16 aligned positions of one slot, the
+        # scatter elsewhere): same bits as the two-step form, both head sizes, lora_scale 2 and 1 (the epilogue's two instantiations),
+        # and with the last sequences shifted so that their strips are NOT aligned (512-token sequences are; 300 / 212 / 640 / 384
+        # start on multiples of 4 only)
+        for scale in (2.0, 1.0):
+            kc0, vt0 = mk()
+            q0 = ops.qkv_rope_cache(ops.linear(x, w, epilogue=ops.EPI_LORA, xa=xa, lora_b=B16, lora_scale=scale, splits=(d, d + kv)),
+                                    cos, sin, slot, pos, kc0, vt0, n_head, n_groups)
+            kc2, vt2 = mk()
+            q2 = ops.linear_qkv_lora_rope_cache(x, w, A48, B16, cos, sin, slot, pos, kc2, vt2, n_head, n_groups, lora_scale=scale)
+            assert torch.equal(q0, q2), f"in-GEMM LoRA, scale {scale}: rotated q differs"
+            assert torch.equal(kc0, kc2), f"in-GEMM LoRA, scale {scale}: K cache differs"
+            assert torch.equal(vt0, vt2), f"in-GEMM LoRA, scale {scale}: V^T cache differs"
+        # a cached prefix: positions start at 37 (no strip is aligned to 16 keys): the scatter path everywhere
+        s_big = s_max + 64
+        cosb, sinb = (t.to(dev) for t in O.build_rope_cache(s_big, hs))
+        mkb = lambda: (torch.zeros((B, n_groups, s_big, hs), dtype=torch.bfloat16, device=dev),
+                       torch.zeros((B, n_groups, hs, s_big), dtype=torch.bfloat16, device=dev))
+        pos37 = pos + 37
+        kc0, vt0 = mkb()
+        q0 = ops.qkv_rope_cache(ops.linear(x, w, epilogue=ops.EPI_LORA, xa=xa, lora_b=B16, lora_scale=2.0, splits=(d, d + kv)),
+                                cosb, sinb, slot, pos37, kc0, vt0, n_head, n_groups)
+        kc2, vt2 = mkb()
+        q2 = ops.linear_qkv_lora_rope_cache(x, w, A48, B16, cosb, sinb, slot, pos37, kc2, vt2, n_head, n_groups, lora_scale=2.0)
+        assert torch.equal(q0, q2) and torch.equal(kc0, kc2) and torch.equal(vt0, vt2), "in-GEMM LoRA, shifted positions"
 
 
 @pytest.mark.parametrize("M,d,I", [(50, 256, 384), (200, 2048, 5632), (300, 256, 384), (515, 2048, 5632)])
