@@ -29,6 +29,8 @@
 #include "gemm.h"
 
 int g_w4_fast_epi = 3;  // dh_set_tuning(24, bits): bit 0 the fused-QKV epilogue of full tiles in its v_dot2_f32_bf16 form (g256_epilogue_qkv_fast), bit 1 the same arithmetic in the LoRA / residual epilogues; 0 = the round-3 forms (A/B)
+int g_w4_persist_qkv = 0;   // dh_set_tuning(25, 0 | 1): persistent blocks for the fused-QKV GEMM with the in-GEMM LoRA.  OFF: measured 374-384 us per launch
+                            // against 373-374 per-tile (same box, round 4): the tile loop keeps the K loop's invariants live across the epilogue (45 spilled registers)
 int g_w4_persist = 1;   // dh_set_tuning(22, 0 | 1 | 2): the 4-wave kernel walks the tiles with one block per CU: never / where the epilogue loads nothing / always
 
 namespace {
@@ -477,9 +479,9 @@ __device__ __forceinline__ void g256_epilogue(const GemmArgs& a, f32x4 (&acc)[8]
 //     {4..7, 12..15} — the 8-key run of the cache's fragment order (common.h vfrag_off) — i.e. one 16-byte store instead of eight
 //     2-byte ones.  Other strips keep the scatter.
 // `vimg`: 4 KiB of LDS per wave (HS 128: [16][128 + 8] bf16).
-template <int HS, bool SCALE1>
+template <int HS, bool SCALE1, class Hook>
 __device__ __forceinline__ void g256_epilogue_qkv_fast(const GemmArgs& a, f32x4 (&acc)[8][8], const int m0, const int n0, const int wn,
-                                                       const int wm, const int lane, const char* xs, char* vimg) {
+                                                       const int wm, const int lane, const char* xs, char* vimg, Hook&& next_tile_dma) {
     constexpr int HALF = HS / 2, H2T = HS / 32, NH = 128 / HS, HT = HS / 16;      // tiles per half head, heads per wave, tiles per head
     constexpr int VSTR = (HS + 8) * 2;                                            // bytes per key row of the V image (8-byte aligned rows)
     const int frow = lane & 15, kg = lane >> 4;
@@ -553,6 +555,10 @@ __device__ __forceinline__ void g256_epilogue_qkv_fast(const GemmArgs& a, f32x4 
         uint2 rope1[4 * H2T];
         load_rope(pos1, rope1);
         const bf16x8 xf1 = load_xf(j + 1 < 8 ? j + 1 : 7);
+        // persistent blocks: the NEXT tile's first two stages are requested here — behind the last loads this epilogue will consume
+        // (strip 7's rope rows were just requested; loads return in order, so a DMA burst in front of them would delay them by the
+        // 64 KiB it moves) and with two strips (~3.4 us) of work left to cover its latency
+        if (j == 6) next_tile_dma();
         const int m = mw0 + j * 16 + frow, pos = pos0, slot = slot0;
         const bool m_ok = m < a.M;
         // the strip's eight LoRA MFMAs (rank 16 zero-padded to K = 32) back to back, straight into VGPRs: through the builtin the
@@ -1221,12 +1227,22 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
         const int vb_next = vb + (int)gridDim.x;
         const bool more = PERSIST && vb_next < nwg;
         int m0n = 0, n0n = 0;
+        constexpr bool LATE_DMA = EPI == DH_EPI_QKV && XA;     // requested from inside the epilogue (its hook)
         if (more) {
-            __builtin_amdgcn_s_barrier();            // every wave has read its last fragments: both buffers are free
             g256_tile_origin<EPI>(a, vb_next, m0n, n0n);
-            setup_src(m0n, n0n);
-            first_stages();
+            if constexpr (!LATE_DMA) {
+                __builtin_amdgcn_s_barrier();        // every wave has read its last fragments: both buffers are free
+                setup_src(m0n, n0n);
+                first_stages();
+            }
         }
+        // (XA kernels: the barrier behind the x.A^T image above already stands between every wave's last fragment read and this point)
+        auto next_tile_dma = [&]() __attribute__((always_inline)) {
+            if (more) {
+                setup_src(m0n, n0n);                 // (recomputed behind the epilogue: kept live across its last strips the 17 offsets spill)
+                first_stages();
+            }
+        };
         G256_STAMP(2);
         const bool full = m0 + BT2 <= a.M && n0 + (EPI == DH_EPI_SWIGLU ? 128 : BT2) <= a.N;
         if constexpr (EPI == DH_EPI_QKV && XA) {
@@ -1234,11 +1250,11 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
             // same kernel costs the register allocator's spill decisions in the code both share (51 scratch accesses per tile behind the K loop)
             char* vimg = smem + 2 * BUF + 256 * 32;
             if (a.hs == 64) {
-                if (a.lora_scale == 1.f) g256_epilogue_qkv_fast<64, true>(a, acc, m0, n0, wn, wm, lane, xs_img, vimg);
-                else g256_epilogue_qkv_fast<64, false>(a, acc, m0, n0, wn, wm, lane, xs_img, vimg);
+                if (a.lora_scale == 1.f) g256_epilogue_qkv_fast<64, true>(a, acc, m0, n0, wn, wm, lane, xs_img, vimg, next_tile_dma);
+                else g256_epilogue_qkv_fast<64, false>(a, acc, m0, n0, wn, wm, lane, xs_img, vimg, next_tile_dma);
             } else {
-                if (a.lora_scale == 1.f) g256_epilogue_qkv_fast<128, true>(a, acc, m0, n0, wn, wm, lane, xs_img, vimg);
-                else g256_epilogue_qkv_fast<128, false>(a, acc, m0, n0, wn, wm, lane, xs_img, vimg);
+                if (a.lora_scale == 1.f) g256_epilogue_qkv_fast<128, true>(a, acc, m0, n0, wn, wm, lane, xs_img, vimg, next_tile_dma);
+                else g256_epilogue_qkv_fast<128, false>(a, acc, m0, n0, wn, wm, lane, xs_img, vimg, next_tile_dma);
             }
         } else {
             if (full) g256_epilogue<EPI, RESID, 8, true, XA>(a, acc, m0, n0, wn, wm, lane, xs_img);
@@ -1249,6 +1265,10 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
         vb = vb_next;
         m0 = m0n;
         n0 = n0n;
+        if constexpr (LATE_DMA) {
+            asm volatile("" ::: "memory");
+            setup_src(m0, n0);                       // the K loop's own copy of the DMA offsets
+        }
     }
 }
 
@@ -1292,7 +1312,11 @@ int launch_w4(const GemmArgs& a, hipStream_t s) {
     // The next tile's first stages are requested in front of the epilogue; loads return in order, so an epilogue that loads
     // (residual, x.A^T fragments, rope rows) would wait for those 64 KiB behind its first operand: persistent blocks only where
     // the epilogue reads nothing (bench: all-persistent 715 utt/s, none 724)
-    if constexpr (EPI == DH_EPI_LORA || EPI == DH_EPI_QKV) {
+    if constexpr (EPI == DH_EPI_QKV) {
+        // round 4 (VERDICT r03 #1a): persistent fused-QKV tiles whose epilogue requests the next tile's stages itself, late (see its hook): built, bit-equal, not faster — off
+        if (a.lora_a != nullptr) return g_w4_persist_qkv ? launch_w4p<EPI, RESID, true, true>(a, s) : launch_w4p<EPI, RESID, false, true>(a, s);
+    }
+    if constexpr (EPI == DH_EPI_LORA) {
         if (a.lora_a != nullptr) return launch_w4p<EPI, RESID, false, true>(a, s);      // w4_xa_ok checked by the caller
     }
     const bool persist = g_w4_persist == 2 || (g_w4_persist == 1 && !RESID && (EPI == DH_EPI_PLAIN || EPI == DH_EPI_SWIGLU));
