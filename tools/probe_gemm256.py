@@ -23,7 +23,6 @@ def stamps(n):
     out = np.zeros((8192, 16), dtype=np.int64)
     out[:, :slots] = buf[:8192 * slots].reshape(8192, slots).astype(np.int64)
     return out[:n]
-import os
 lib.dh_set_tuning(1, int(os.environ.get("G256_VARIANT", "5")))      # 1: 8-wave ping-pong, 5: 4-wave full-line
 lib.dh_set_tuning(22, 0)     # per-tile launches: a block = a tile
 H, G, hs, S = 32, 4, 64, 512
@@ -50,12 +49,8 @@ for (nm, fn, nblk) in (("SwiGLU (K 2048)", lambda: ops.linear(x, W1, epilogue=op
         v = seg[:, j]
         print(f"   {n:32s} median {np.median(v):6.2f}  p10 {np.percentile(v, 10):6.2f}  p90 {np.percentile(v, 90):6.2f} us")
     # gap between consecutive tiles on the same CU cannot be read from block ids; estimate from occupancy:
-    if nm.startswith("QKV") and st[:, 4].max() > 0:      # the fast fused-QKV epilogue's own stamps: set-up done, then the start of each 16-row strip
-        inner = np.stack([st[:, 4] - st[:, 2]] + [st[:, 5 + k] - st[:, 4 + k] for k in range(8)] + [st[:, 3] - st[:, 12]], 1) * 0.01
-        print("   fast QKV epilogue, median us: loop end -> set-up issued, set-up -> strip 0, strips 0..6, strip 7 -> end:", np.round(np.median(inner, 0), 2).tolist())
-        print("   G256_FAST_EPI bit 7: strip 3 start -> pair 0 -> pair 1 -> pair 2 done, median us:", np.round(np.median(np.stack([st[:, 13] - st[:, 8], st[:, 14] - st[:, 13], st[:, 15] - st[:, 14]], 1) * 0.01, 0), 2).tolist())
-        print("   slots 13 -> 14 (G256_FAST_EPI bit 6: 32 bare accumulator reads) median us:", float(np.median((st[:, 14] - st[:, 13]) * 0.01)))
-        sub = np.stack([st[:, 13] - st[:, 8], st[:, 14] - st[:, 13], st[:, 15] - st[:, 14], st[:, 9] - st[:, 15]], 1) * 0.01
-        print("   strip 3, median us: LoRA finish, masks, first head (rope + stores), second head:", np.round(np.median(sub, 0), 2).tolist())
+    if nm.startswith("QKV") and st[:, 4].max() > 0:      # the fused-QKV epilogue's own stamp: its set-up (positions, rope rows, x.A^T rows of strip 0) issued
+        inner = np.stack([st[:, 4] - st[:, 2], st[:, 3] - st[:, 4]], 1) * 0.01
+        print("   fused-QKV epilogue, median us: loop end -> set-up issued, the 8 strips:", np.round(np.median(inner, 0), 2).tolist())
     busy = seg[:, 3].sum() / 256
     print(f"   sum of tile times / 256 CUs = {busy:.1f} us of the {(st[:, 3].max() - t0) * 0.01:.1f} us span")
