@@ -54,6 +54,7 @@ SIGNATURES = {
     "dh_attn_prefill_bf16": (I, [P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "dh_dropout_bf16": (I, [P, P, P, I64, F, C.c_uint64, C.c_uint32, P, P]),
     "dh_swiglu_fwd_bf16": (I, [P, P, P, I64, P]),
+    "dh_linear_swiglu_train_bf16": (I, [P, P, P, P, P, P, I, I, I, P]),
     "dh_swiglu_bwd_bf16": (I, [P, P, P, P, I, I, P]),
     "dh_rmsnorm_bwd_bf16": (I, [P, P, P, P, P, I, I, F, P]),
     "dh_qkv_rope_bwd_bf16": (I, [P, P, P, P, P, P, P, I, I, I, I, P]),
@@ -61,6 +62,7 @@ SIGNATURES = {
     "dh_tn_accum_work_bytes": (I64, [I, I, I]),
     "dh_rowdot_f32": (I, [P, P, P, I64, I, P]),
     "dh_transpose_pad_bf16": (I, [P, P, P, P, P, I, I, I, I, P]),
+    "dh_transpose_frag_bf16": (I, [P, P, P, I, I, I, P]),
     "dh_attn_bwd_bf16": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "dh_attn_decode_work_bytes": (I64, [I, I, I, I]),
     "dh_attn_decode_bf16": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),
@@ -112,7 +114,7 @@ def load() -> C.CDLL:
             raise DualHypHipError(f"libdualhyp_hip.so does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.dh_abi_version() != 5:
+    if lib.dh_abi_version() != 6:
         raise DualHypHipError("libdualhyp_hip.so ABI version mismatch")
     _lib = lib
     return lib

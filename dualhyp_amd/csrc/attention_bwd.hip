@@ -61,6 +61,41 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const bf16_t* __rest
     }
 }
 
+// Round 4: the same copy with 16-byte accesses on both sides.  One block per padded 32-token tile and head: the tile's rows come in
+// as 16-byte chunks (token of padded position p = pad_tok[p], -1 = padding -> zeros, so the destination needs no memset), go through a
+// [32][hs + 8] LDS image, and ds_read_b64_tr_b16 (cdna_hip_programming.md T10) hands lane (lh, channel) its 4 + 4 tokens: the tile's
+// 2 x hs/32 fragments leave as whole 1-KiB wave stores.  (The kernel above moves 2 bytes per lane each way: 80 us per call on the
+// packed 17 920-token micro-step, 1.8 TB/s.)
+template <int HS>
+__global__ __launch_bounds__(256) void transpose_frag_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                             const int32_t* __restrict__ pad_tok, int heads, int n_pad) {
+    constexpr int STR = (HS + 8) * 2, DT = HS / 32;
+    __shared__ __attribute__((aligned(16))) char tile[32 * STR];
+    const int pt = blockIdx.x, h = blockIdx.y;
+#pragma unroll
+    for (int it = threadIdx.x; it < 32 * (HS / 8); it += 256) {
+        const int tl = it / (HS / 8), c = it % (HS / 8);
+        const int tok = pad_tok[pt * 32 + tl];
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (tok >= 0) v = *reinterpret_cast<const uint4*>(src + ((size_t)tok * heads + h) * HS + c * 8);
+        *reinterpret_cast<uint4*>(tile + tl * STR + c * 16) = v;
+    }
+    __syncthreads();
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3, lh = g >> 1;
+#pragma unroll
+    for (int f = wave; f < 2 * DT; f += 4) {                      // fragment (s2, dt) of the tile
+        const int s2 = f / DT, dt = f % DT;
+        const char* rd = tile + (16 * s2 + 4 * lh + q) * STR + (dt * 32 + (g & 1) * 16 + 4 * p) * 2;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)rd);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(rd + 8 * STR));
+        const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+        *reinterpret_cast<uint4*>(dst + tfrag_lane<HS>(h, n_pad, pt, s2, dt, lane)) = make_uint4(l2.x, l2.y, h2.x, h2.y);
+    }
+}
+
 template <int HS, int QPKT>   // QPKT <= query heads per group (block = 64 x that many threads): sizes the per-thread totals
 __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
@@ -355,6 +390,17 @@ extern "C" int dh_transpose_pad_bf16(const dh_bf16* src, dh_bf16* dst, const int
     if (n_tok <= 0) return 0;
     hipLaunchKernelGGL(transpose_pad_kernel, dim3(cdiv(n_tok, 32), heads), dim3(256), 0, (hipStream_t)stream, src, dst, tok_seq,
                        q_start, pad_start, n_tok, heads, hs, n_pad);
+    DH_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dh_transpose_frag_bf16(const dh_bf16* src, dh_bf16* dst, const int32_t* pad_tok, int heads, int hs, int n_pad,
+                                      void* stream) {
+    DH_CHECK(src && dst && pad_tok && (hs == 64 || hs == 128) && heads > 0 && n_pad >= 0 && n_pad % 32 == 0, "dh_transpose_frag_bf16: bad argument");
+    DH_CHECK(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0, "dh_transpose_frag_bf16: src / dst must be 16-byte aligned");
+    if (n_pad == 0) return 0;
+    if (hs == 64) hipLaunchKernelGGL((transpose_frag_kernel<64>), dim3(n_pad / 32, heads), dim3(256), 0, (hipStream_t)stream, src, dst, pad_tok, heads, n_pad);
+    else hipLaunchKernelGGL((transpose_frag_kernel<128>), dim3(n_pad / 32, heads), dim3(256), 0, (hipStream_t)stream, src, dst, pad_tok, heads, n_pad);
     DH_LAUNCH_CHECK();
     return 0;
 }

@@ -334,6 +334,31 @@ extern "C" int dh_linear_lora_bf16(const dh_bf16* x, const dh_bf16* w, dh_bf16* 
     return dh_linear_lora_impl(x, w, y, M, N, K, lora_a, lora_b, lora_scale, split0, split1, resid, xa_work, g_linear_phase, (hipStream_t)stream);
 }
 
+// Training forward of the MLP's first half in ONE launch (round 4; finetune/ger.py:278-292 keeps fc_1(n2) and fc_2(n2) for the backward):
+// the SwiGLU GEMM whose epilogue also stores the rounded pre-activations.  g = bf16(x.W1^T), u = bf16(x.W2^T), act = bf16(bf16(silu(g)) * u)
+// — the bits of two plain GEMMs followed by dh_swiglu_fwd_bf16 (the same accumulator chain per output), which is also the fallback
+// below the 256-tile kernel's range.
+extern "C" int dh_swiglu_fwd_bf16(const dh_bf16* g, const dh_bf16* u, dh_bf16* act, int64_t n, void* stream);
+extern "C" int dh_linear_swiglu_train_bf16(const dh_bf16* x, const dh_bf16* w1, const dh_bf16* w2, dh_bf16* act, dh_bf16* g, dh_bf16* u,
+                                           int M, int I, int K, void* stream) {
+    DH_CHECK(x && w1 && w2 && act && g && u, "dh_linear_swiglu_train_bf16: null argument");
+    DH_CHECK(M >= 0 && I > 0 && K > 0 && K % BK == 0 && I % 32 == 0, "dh_linear_swiglu_train_bf16: bad shape M=%d I=%d K=%d", M, I, K);
+    if (M == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (M > 32 && dh_linear_is_big(M, I, DH_EPI_SWIGLU)) {
+        GemmArgs a{};
+        a.x = x; a.w = w1; a.w2 = w2; a.y = act; a.M = M; a.N = I; a.K = K; a.lora_scale = 1.f;
+        a.resid = g;                     // selects the kernels' RESID instantiation (= "store g and u" for this epilogue; never read)
+        a.q_out = g; a.k_cache = u;
+        return dh_linear_256(a, DH_EPI_SWIGLU, s);
+    }
+    int rc = dh_linear_impl(x, w1, g, M, I, K, DH_EPI_PLAIN, nullptr, nullptr, 0, nullptr, 1.f, 0, 0, nullptr, nullptr, nullptr, g_linear_phase, s);
+    if (rc) return rc;
+    rc = dh_linear_impl(x, w2, u, M, I, K, DH_EPI_PLAIN, nullptr, nullptr, 0, nullptr, 1.f, 0, 0, nullptr, nullptr, nullptr, g_linear_phase, s);
+    if (rc) return rc;
+    return dh_swiglu_fwd_bf16(g, u, act, (int64_t)M * I, stream);
+}
+
 int dh_linear_impl(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N, int K, int epilogue,
                    const dh_bf16* w2, const dh_bf16* xa, int xa_ld, const dh_bf16* lora_b, float lora_scale,
                    int split0, int split1, const dh_bf16* vec_a, const dh_bf16* vec_b, const dh_bf16* resid,

@@ -136,6 +136,10 @@ __device__ __forceinline__ uint2 rope_half(uint32_t ax, uint32_t ay, uint32_t bx
 template <int EPI, bool RESID, int MJ, bool FULL, bool XS = false>
 __device__ __forceinline__ void g256_epilogue(const GemmArgs& a, f32x4 (&acc)[8][MJ], const int m0, const int n0, const int wn,
                                               const int wm, const int lane, const char* xs = nullptr) {
+    // SWIGLU with the RESID flag set is the TRAINING forward (dh_linear_swiglu_train_bf16): no residual is read; the epilogue also
+    // stores the rounded pre-activations g = bf16(acc1) -> a.q_out and u = bf16(acc2) -> a.k_cache ([M, N] like y) that the backward needs
+    constexpr bool GU = EPI == DH_EPI_SWIGLU && RESID;
+    constexpr bool RES = RESID && !GU;
     const int frow = lane & 15, kg = lane >> 4;
     const int mw0 = m0 + wm * (MJ * 16);
     // ---------------------------------------------------------------- epilogue
@@ -178,8 +182,8 @@ __device__ __forceinline__ void g256_epilogue(const GemmArgs& a, f32x4 (&acc)[8]
     // proj + LoRA + residual 20.8 -> ?? us per tile)
     constexpr int PD = MJ == 8 ? 4 : 2;
     bf16x8 xfv2[PD][LORA ? NT / 2 : 1];
-    uint4 rrv2[PD][RESID ? NT / 2 : 1];
-    auto load_strip = [&](int j, bf16x8 (&xf)[LORA ? NT / 2 : 1], uint4 (&rr)[RESID ? NT / 2 : 1]) __attribute__((always_inline)) {
+    uint4 rrv2[PD][RES ? NT / 2 : 1];
+    auto load_strip = [&](int j, bf16x8 (&xf)[LORA ? NT / 2 : 1], uint4 (&rr)[RES ? NT / 2 : 1]) __attribute__((always_inline)) {
         const int m = mw0 + j * 16 + frow;
         const bool m_ok = FULL || m < a.M;
         if constexpr (XS) {
@@ -199,7 +203,7 @@ __device__ __forceinline__ void g256_epilogue(const GemmArgs& a, f32x4 (&acc)[8]
         }
         // residual in the layout of the paired 16-byte stores below (8 consecutive columns per lane): the add is done
         // after the permlane swap, on values that are already bf16-exact, so the rounding is that of bf16(resid + y)
-        if (RESID) {
+        if (RES) {
 #pragma unroll
             for (int ip = 0; ip < NT / 2; ++ip) {
                 const int nb = nw0 + ip * 32;
@@ -255,7 +259,7 @@ __device__ __forceinline__ void g256_epilogue(const GemmArgs& a, f32x4 (&acc)[8]
         const bool m_ok = FULL || m < a.M;
         if constexpr (j + PD - 1 < MJ) load_strip(j + PD - 1, xfv2[(j + PD - 1) % PD], rrv2[(j + PD - 1) % PD]);
         bf16x8 (&xfv)[LORA ? NT / 2 : 1] = xfv2[j % PD];
-        uint4 (&rrv)[RESID ? NT / 2 : 1] = rrv2[j % PD];
+        uint4 (&rrv)[RES ? NT / 2 : 1] = rrv2[j % PD];
         if constexpr (EPI == DH_EPI_QKV && j + 1 < MJ) load_rope(j + 1, ropev[(j + 1) & 1]);
         uint2 (&rp)[EPI == DH_EPI_QKV ? 16 : 1] = ropev[j & 1];
         if constexpr (EPI == DH_EPI_QKV) {
@@ -396,7 +400,7 @@ __device__ __forceinline__ void g256_epilogue(const GemmArgs& a, f32x4 (&acc)[8]
             uint2 ta, tb;
 #ifndef DH_W4_OLD_EPI
             // round 4, the 4-wave kernel's full tiles: "round both, add" of the LoRA finish as v_cvt_pk + v_dot2 (see dot2_sum8_pack)
-            constexpr bool DOT = FULL && MJ == 8 && ((EPI == DH_EPI_LORA && XS) || (EPI == DH_EPI_PLAIN && RESID));   // (LoRA with xa from memory: 8 spilled registers)
+            constexpr bool DOT = FULL && MJ == 8 && ((EPI == DH_EPI_LORA && XS) || (EPI == DH_EPI_PLAIN && RES));   // (LoRA with xa from memory: 8 spilled registers)
 #else
             constexpr bool DOT = false;
 #endif
@@ -423,13 +427,31 @@ __device__ __forceinline__ void g256_epilogue(const GemmArgs& a, f32x4 (&acc)[8]
                 tb = tile_value(2 * ip + 1);
             }
             const int nb = nw0 + ip * 32;                        // first column of the pair (wave-uniform)
+            if constexpr (GU) {
+                auto pk = [&](int i) __attribute__((always_inline)) -> uint2 {
+                    return make_uint2(pack2bf(acc[i][j][0], acc[i][j][1]), pack2bf(acc[i][j][2], acc[i][j][3]));
+                };
+                auto put = [&](bf16_t* dst, uint2 va, uint2 vb) __attribute__((always_inline)) {
+                    if (FULL || nb + 32 <= a.N) {
+                        const auto rx = __builtin_amdgcn_permlane16_swap(va.x, vb.x, false, false);
+                        const auto ry = __builtin_amdgcn_permlane16_swap(va.y, vb.y, false, false);
+                        if (m_ok) *reinterpret_cast<uint4*>(dst + (size_t)m * a.N + nb + (kg & 1) * 16 + (kg >> 1) * 8) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+                    } else {
+                        const int na = nb + kg * 4;
+                        if (m_ok && na < a.N) *reinterpret_cast<uint2*>(dst + (size_t)m * a.N + na) = va;
+                        if (m_ok && na + 16 < a.N) *reinterpret_cast<uint2*>(dst + (size_t)m * a.N + na + 16) = vb;
+                    }
+                };
+                put(a.q_out, pk(2 * ip), pk(2 * ip + 1));
+                put(a.k_cache, pk(2 * ip + 4), pk(2 * ip + 5));
+            }
             if (FULL || nb + 32 <= a.N) {
                 const auto rx = __builtin_amdgcn_permlane16_swap(ta.x, tb.x, false, false);
                 const auto ry = __builtin_amdgcn_permlane16_swap(ta.y, tb.y, false, false);
                 uint4 out = make_uint4(rx[0], ry[0], rx[1], ry[1]);
-                if constexpr (RESID && DOT) {
+                if constexpr (RES && DOT) {
                     // bf16(resid + y) on 8 values: (y, r) pairs by v_perm, then the same "add the two halves" block
-                    const uint4 rr = rrv[RESID ? ip : 0];
+                    const uint4 rr = rrv[RES ? ip : 0];
                     const uint32_t yv[4] = {out.x, out.y, out.z, out.w}, rv[4] = {rr.x, rr.y, rr.z, rr.w};
                     uint32_t pk[8];
 #pragma unroll
@@ -438,8 +460,8 @@ __device__ __forceinline__ void g256_epilogue(const GemmArgs& a, f32x4 (&acc)[8]
                         pk[2 * q + 1] = __builtin_amdgcn_perm(rv[q], yv[q], 0x07060302u);   // (y hi, r hi)
                     }
                     dot2_sum8_pack(pk, out.x, out.y, out.z, out.w);
-                } else if (RESID) {
-                    const uint4 rr = rrv[RESID ? ip : 0];
+                } else if (RES) {
+                    const uint4 rr = rrv[RES ? ip : 0];
                     auto add2 = [](uint32_t y2, uint32_t r2) __attribute__((always_inline)) -> uint32_t {
                         return pack2bf(bf2f((bf16_t)(r2 & 0xffffu)) + bf2f((bf16_t)(y2 & 0xffffu)),
                                        bf2f((bf16_t)(r2 >> 16)) + bf2f((bf16_t)(y2 >> 16)));
@@ -450,7 +472,7 @@ __device__ __forceinline__ void g256_epilogue(const GemmArgs& a, f32x4 (&acc)[8]
             } else {                                             // a pair straddling N: the narrow stores
                 const int na = nb + kg * 4;
                 auto with_resid = [&](uint2 t, int n) __attribute__((always_inline)) -> uint2 {
-                    if (!RESID) return t;
+                    if (!RES) return t;
                     const uint2 rr = *reinterpret_cast<const uint2*>(a.resid + (size_t)m * a.N + n);
                     return make_uint2(pack2bf(bf2f((bf16_t)(rr.x & 0xffffu)) + bf2f((bf16_t)(t.x & 0xffffu)),
                                               bf2f((bf16_t)(rr.x >> 16)) + bf2f((bf16_t)(t.x >> 16))),
@@ -1319,7 +1341,7 @@ int launch_w4(const GemmArgs& a, hipStream_t s) {
     if constexpr (EPI == DH_EPI_LORA) {
         if (a.lora_a != nullptr) return launch_w4p<EPI, RESID, false, true>(a, s);      // w4_xa_ok checked by the caller
     }
-    const bool persist = g_w4_persist == 2 || (g_w4_persist == 1 && !RESID && (EPI == DH_EPI_PLAIN || EPI == DH_EPI_SWIGLU));
+    const bool persist = g_w4_persist == 2 || (g_w4_persist == 1 && ((!RESID && EPI == DH_EPI_PLAIN) || EPI == DH_EPI_SWIGLU));
     return persist ? launch_w4p<EPI, RESID, true>(a, s) : launch_w4p<EPI, RESID, false>(a, s);
 }
 

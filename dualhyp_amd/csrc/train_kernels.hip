@@ -4,6 +4,8 @@
 // fp32, LoRA gradients are accumulated in fp32 buffers.
 #include "common.h"
 
+int g_tn_mfma = 1;    // dh_set_tuning(26, 0): the LoRA-gradient contraction on the VALU kernel of rounds 2-3 (A/B)
+
 namespace {
 
 // ---------------------------------------------------------------------------------- SwiGLU backward
@@ -238,6 +240,133 @@ __global__ __launch_bounds__(1024) void tn_accum_wide_kernel(const bf16_t* __res
     }
 }
 
+// Round 4: the same contraction on the matrix pipe.  The kernel above reads its large operand two bytes per lane and spends ~35
+// VALU instructions per token and wave (181 / 58 us per call on the packed 17 920-token micro-step, 0.4 / 1.3 TB/s); the FLOPs are
+// nothing (16 output rows), the bytes are everything, and both operands have the contraction index (the token) as their ROW index
+// while v_mfma_f32_16x16x32_bf16 wants 8 consecutive k per lane.  So: a block owns 128 columns of the large operand and a chunk
+// of tokens; stages of 64 tokens go HBM -> LDS by LDS-DMA in whole 256-byte row pieces (three stages, two in flight), and
+// ds_read_b64_tr_b16 (cdna_hip_programming.md T10) hands each lane its 4 + 4 tokens of one column: D[s][l] += small^T . large.
+//   large image of a stage: 16 pieces of 1 KiB = 4 tokens x 256 B, chunk-major inside a piece (16-byte chunk c of token q at
+//   (4 c + q) * 16: the four rows of a transposed read sit in 64 consecutive bytes -> conflict-free inside a 16-lane group);
+//   small image(s): [token][32 B] per 16-wide group.
+// The sums are fp32 in the MFMA's order (k ascending inside a chunk), chunks added by tn_reduce_kernel in index order as before:
+// deterministic; not the bits of the VALU kernel (tests compare with torch fp32 to 2e-5).
+template <bool LARGE_IS_M, int SB>
+__global__ __launch_bounds__(256, 2) void tn_accum_mfma_kernel(const bf16_t* __restrict__ a, int lda, const bf16_t* __restrict__ b,
+                                                               int ldb, float* __restrict__ out, int ldo, int T, int M, int N,
+                                                               float scale, int accumulate, int tchunk) {
+    if (gridDim.z > 1) {
+        const int t_begin = blockIdx.z * tchunk;
+        a += (size_t)t_begin * lda;
+        b += (size_t)t_begin * ldb;
+        T = min(T - t_begin, tchunk);
+        out += (size_t)blockIdx.z * M * N;      // part[z], dense [M][N]
+        ldo = N; scale = 1.f; accumulate = 0;
+    }
+    constexpr int LC = 128, TS = 64, NST = 3;
+    constexpr int BIG_B = TS * LC * 2, SM_B = TS * 32 * SB, STAGE = BIG_B + SM_B;
+    constexpr int NPW = 4 + (SB == 1 ? 1 : 2);          // DMA pieces per wave and stage (every wave the same number: counted waits)
+    extern __shared__ __attribute__((aligned(16))) char tn_smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bf16_t* big = LARGE_IS_M ? a : b;
+    const bf16_t* small = LARGE_IS_M ? b : a;
+    const int ldbig = LARGE_IS_M ? lda : ldb, ldsm = LARGE_IS_M ? ldb : lda;
+    const int L = LARGE_IS_M ? M : N;
+    const int l0 = blockIdx.x * LC, s0 = blockIdx.y * 16 * SB;
+    // ---- DMA sources.  large piece pi of a stage: tokens 4 pi + (lane & 3), 16-byte chunk lane >> 2 of the block's 256 bytes (clamped
+    // to the row's last chunk: L % 8 == 0); wave w moves pieces 4 w .. 4 w + 3.  small piece sp: image sp >> 1, tokens 32 (sp & 1) + lane / 2.
+    const int colc = min(l0 + 8 * (lane >> 2), L - 8);
+    const int n_sp = 2 * SB;
+    auto big_off = [&](int j, int t_stage) __attribute__((always_inline)) -> uint32_t {
+        const int t = min(t_stage + 16 * wave + 4 * j + (lane & 3), T - 1);
+        return ((uint32_t)t * (uint32_t)ldbig + (uint32_t)colc) * 2u;
+    };
+    auto small_piece = [&](int k) __attribute__((always_inline)) -> int { return SB == 1 ? (wave & 1) : (2 * (wave % 3) + k); };
+    auto small_off = [&](int sp, int t_stage) __attribute__((always_inline)) -> uint32_t {
+        const int t = min(t_stage + 32 * (sp & 1) + (lane >> 1), T - 1);
+        return ((uint32_t)t * (uint32_t)ldsm + (uint32_t)(s0 + 16 * (sp >> 1) + 8 * (lane & 1))) * 2u;
+    };
+    (void)n_sp;
+    auto issue = [&](int st) __attribute__((always_inline)) {
+        char* base = tn_smem + (st % NST) * STAGE;
+        const int t_stage = st * TS;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16_saddr(big, big_off(j, t_stage), base + (4 * wave + j) * 1024);
+#pragma unroll
+        for (int k = 0; k < NPW - 4; ++k) {
+            const int sp = small_piece(k);
+            glds16_saddr(small, small_off(sp, t_stage), base + BIG_B + sp * 1024);
+        }
+    };
+    const int nstages = (T + TS - 1) / TS;
+    f32x4 acc[2][SB];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int sb = 0; sb < SB; ++sb) acc[j][sb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // ---- transposed reads: lane 4 q + p of a 16-lane group gives the address of row q, columns 4 p .. 4 p + 3; lane i receives column i
+    const int kg = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    auto tr = [&](const char* ptr) __attribute__((always_inline)) -> s16x4 { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)ptr); };
+    auto frag = [&](const char* lo, const char* hi) __attribute__((always_inline)) -> bf16x8 {
+        const s16x4 x = tr(lo), y = tr(hi);
+        return bf16x8{x[0], x[1], x[2], x[3], y[0], y[1], y[2], y[3]};
+    };
+#pragma unroll 1
+    for (int st = 0; st < NST - 1 && st < nstages; ++st) issue(st);
+#pragma unroll 1
+    for (int st = 0; st < nstages; ++st) {
+        if (st + NST - 2 < nstages) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                              // stage st has landed for every wave; every wave is done with stage st - 1
+        if (st + NST - 1 < nstages) issue(st + NST - 1);
+        const char* base = tn_smem + (st % NST) * STAGE;
+        const bool tail = (st + 1) * TS > T;          // block-uniform: tokens past T are clamped copies — zero their products
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[SB], bfr[2];
+#pragma unroll
+            for (int sb = 0; sb < SB; ++sb) {
+                const char* img = base + BIG_B + sb * 2048 + (32 * ks + 8 * kg + q) * 32 + 8 * p;
+                af[sb] = frag(img, img + 4 * 32);
+                if (tail) {
+                    union { bf16x8 v; short e[8]; } u;
+                    u.v = af[sb];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (st * TS + 32 * ks + 8 * kg + e >= T) u.e[e] = 0;
+                    af[sb] = u.v;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int ct = 2 * wave + j;
+                const char* blk = base + (8 * ks + 2 * kg) * 1024 + ((2 * ct + (p >> 1)) * 4 + q) * 16 + 8 * (p & 1);
+                bfr[j] = frag(blk, blk + 1024);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int sb = 0; sb < SB; ++sb) acc[j][sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[sb], bfr[j], acc[j][sb], 0, 0, 0);
+        }
+    }
+    // D[s = 4 kg + r][l = 16 ct + (lane & 15)]
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int l = l0 + 16 * (2 * wave + j) + (lane & 15);
+        if (l >= L) continue;
+#pragma unroll
+        for (int sb = 0; sb < SB; ++sb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int s = s0 + 16 * sb + 4 * kg + r;
+                float* o = LARGE_IS_M ? out + (size_t)l * ldo + s : out + (size_t)s * ldo + l;
+                *o = (accumulate ? *o : 0.f) + scale * acc[j][sb][r];
+            }
+    }
+}
+
 // out[m][n] = (accumulate ? out : 0) + scale * (part[0] + part[1] + ... in index order)
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, int nz, float* __restrict__ out, int ldo,
                                                         int M, int N, float scale, int accumulate) {
@@ -383,10 +512,28 @@ extern "C" int dh_tn_accum_f32(const dh_bf16* a, int lda, const dh_bf16* b, int 
         // long token loops (packed micro-batches) are split over the grid's z when the caller brought scratch
         const int nz = work != nullptr && T > 2 * TN_CHUNK ? cdiv(T, TN_CHUNK) : 1;
         float* dst = nz > 1 ? (float*)work : out;
-        // SB = 3 (the 48-row QKV LoRA-A gradient in one block: the large operand read once instead of three times) was measured:
-        // 520 us per call against ~260 — 48 accumulators + 24 operand registers per token round do not fit the 128 VGPRs of a
-        // 1024-thread block.  Not dispatched.
-        if (n_small)
+        // the MFMA form (tn_accum_mfma_kernel): the large operand in aligned 16-byte chunks addressed through 32-bit offsets
+        const bf16_t* big = n_small ? a : b;
+        const int ldbig = n_small ? lda : ldb, L = n_small ? M : N, S = n_small ? N : M, ldsm = n_small ? ldb : lda;
+        const int t_span = nz > 1 ? TN_CHUNK : T;
+        const bool mfma = g_tn_mfma && T > 0 && L % 8 == 0 && ldbig % 8 == 0 && ((uintptr_t)big & 15) == 0 &&
+                          (size_t)t_span * ldbig * 2 < (1ull << 32) && (size_t)t_span * ldsm * 2 < (1ull << 32);
+        if (mfma) {
+            const int sb = S == 48 ? 3 : 1;
+            const dim3 grid(cdiv(L, 128), S / (16 * sb), nz), block(256);
+            const int lds1 = 3 * (64 * 128 * 2 + 64 * 32), lds3 = 3 * (64 * 128 * 2 + 64 * 32 * 3);
+            if (n_small && sb == 1) {
+                hipLaunchKernelGGL((tn_accum_mfma_kernel<true, 1>), grid, block, lds1, st, a, lda, b, ldb, dst, ldo, T, M, N, scale, accumulate, TN_CHUNK);
+            } else if (n_small) {
+                DH_MAX_LDS_ONCE((tn_accum_mfma_kernel<true, 3>), lds3);
+                hipLaunchKernelGGL((tn_accum_mfma_kernel<true, 3>), grid, block, lds3, st, a, lda, b, ldb, dst, ldo, T, M, N, scale, accumulate, TN_CHUNK);
+            } else if (sb == 1) {
+                hipLaunchKernelGGL((tn_accum_mfma_kernel<false, 1>), grid, block, lds1, st, a, lda, b, ldb, dst, ldo, T, M, N, scale, accumulate, TN_CHUNK);
+            } else {
+                DH_MAX_LDS_ONCE((tn_accum_mfma_kernel<false, 3>), lds3);
+                hipLaunchKernelGGL((tn_accum_mfma_kernel<false, 3>), grid, block, lds3, st, a, lda, b, ldb, dst, ldo, T, M, N, scale, accumulate, TN_CHUNK);
+            }
+        } else if (n_small)
             hipLaunchKernelGGL((tn_accum_wide_kernel<true, 1>), dim3(cdiv(M, 64), N / 16, nz), dim3(1024), 0, st, a, lda, b, ldb, dst, ldo,
                                T, M, N, scale, accumulate, TN_CHUNK);
         else

@@ -435,6 +435,18 @@ def swiglu_fwd(g: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
     return act
 
 
+def linear_swiglu_train(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor):
+    """-> (act, g, u): the training forward of fc_1 / fc_2 (ger/model.py:313-315) in one GEMM launch that also keeps the rounded
+    pre-activations for the backward; the bits of linear(x, w1), linear(x, w2), swiglu_fwd(g, u)."""
+    k = _Keep()
+    M, K = x.shape
+    I = w1.size(0)
+    act = torch.empty((M, I), dtype=torch.bfloat16, device=x.device)
+    g, u = torch.empty_like(act), torch.empty_like(act)
+    check(_lib.load().dh_linear_swiglu_train_bf16(k(x), k(w1), k(w2), _p(act), _p(g), _p(u), M, I, K, _stream()))
+    return act, g, u
+
+
 def swiglu_bwd(dact: torch.Tensor, g: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
     k = _Keep()
     rows, I = g.shape
@@ -475,32 +487,47 @@ def tn_accum(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, scale: float =
                               T, M, N, float(scale), int(accumulate), _p(work), _stream()))
 
 
-def attn_bwd(q, k, v, out, dout, lse, q_start, q_len, max_q_len: int, lens: Optional[Sequence[int]] = None):
+def attn_bwd_plan(q_start: torch.Tensor, q_len: torch.Tensor, n_tok: int, lens: Sequence[int]) -> dict:
+    """Index tensors of the padded, fragment-ordered copies dh_attn_bwd_bf16 reads — the same for every layer of a micro-step, so the
+    training step builds them once: pad_start[i] (sequence i starts at a multiple of 32), n_pad, and the inverse map
+    pad_tok[p] = token of padded position p (-1 = padding)."""
+    dev = q_len.device
+    n_pad = sum(-(-n // 32) * 32 for n in lens)
+    pads_dev = (q_len + 31) // 32 * 32
+    pad_start = (torch.cumsum(pads_dev, 0) - pads_dev).to(torch.int32)
+    tok_seq = torch.repeat_interleave(torch.arange(len(lens), dtype=torch.int64, device=dev), q_len.to(torch.int64), output_size=n_tok)
+    tok = torch.arange(n_tok, dtype=torch.int64, device=dev)
+    pp = pad_start.to(torch.int64)[tok_seq] + (tok - q_start.to(torch.int64)[tok_seq])
+    pad_tok = torch.full((n_pad,), -1, dtype=torch.int32, device=dev)
+    pad_tok[pp] = tok.to(torch.int32)
+    return {"n_pad": n_pad, "pad_start": pad_start, "pad_tok": pad_tok, "n_seq": len(lens)}
+
+
+def attn_bwd(q, k, v, out, dout, lse, q_start, q_len, max_q_len: int, lens: Optional[Sequence[int]] = None, plan: Optional[dict] = None):
     """-> (dq, dk, dv) of the causal GQA attention of a packed batch (sequences attend to themselves).
-    `lens` = q_len on the host; when given nothing here touches the host (hipGraph capture of a training step)."""
+    `lens` = q_len on the host; when given nothing here touches the host (hipGraph capture of a training step).
+    `plan` = attn_bwd_plan(...) of the same batch (built once per micro-step by the caller; built here when absent)."""
     keep = _Keep()
     n_tok, H, hs = q.shape
     G = k.size(1)
     lib = _lib.load()
     dev = q.device
-    if lens is None:
-        lens = q_len.tolist()
-    n_pad = sum(-(-n // 32) * 32 for n in lens)
-    pads_dev = (q_len + 31) // 32 * 32
-    pad_start = (torch.cumsum(pads_dev, 0) - pads_dev).to(torch.int32)
-    tok_seq = torch.repeat_interleave(torch.arange(len(lens), dtype=torch.int32, device=dev), q_len.to(torch.int64), output_size=n_tok)
+    if plan is None:
+        if lens is None:
+            lens = q_len.tolist()
+        plan = attn_bwd_plan(q_start, q_len, n_tok, lens)
+    n_pad, pad_start, pad_tok = plan["n_pad"], plan["pad_start"], plan["pad_tok"]
     dout = _dev(dout.reshape(n_tok, H, hs))
     dsum = torch.empty((n_tok, H), dtype=torch.float32, device=dev)
     check(lib.dh_rowdot_f32(_p(dout), keep(out.reshape(n_tok, H, hs)), _p(dsum), n_tok * H, hs, _stream()))
 
     def tpad(src, heads):
-        dst = torch.zeros((heads, hs, n_pad), dtype=torch.bfloat16, device=dev)
-        check(lib.dh_transpose_pad_bf16(keep(src), _p(dst), _p(tok_seq), _p(q_start), _p(pad_start), n_tok, heads, hs,
-                                        n_pad, _stream()))
+        dst = torch.empty((heads, hs, n_pad), dtype=torch.bfloat16, device=dev)      # padding is written (zeros) by the kernel
+        check(lib.dh_transpose_frag_bf16(keep(src), _p(dst), _p(pad_tok), heads, hs, n_pad, _stream()))
         return dst
     qT, doT, kT = tpad(q, H), tpad(dout, H), tpad(k, G)
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     check(lib.dh_attn_bwd_bf16(keep(q, name="q"), keep(k, name="k"), keep(v, name="v"), _p(dout), _p(qT), _p(doT), _p(kT), _p(lse), _p(dsum), _p(q_start),
-                               _p(q_len), _p(pad_start), _p(dq), _p(dk), _p(dv), len(lens), int(max_q_len), H, G, hs,
+                               _p(q_len), _p(pad_start), _p(dq), _p(dk), _p(dv), plan["n_seq"], int(max_q_len), H, G, hs,
                                n_pad, _stream()))
     return dq, dk, dv

@@ -127,6 +127,16 @@ def _dropout_state(model, dev):
     return st
 
 
+def _masked(lo: torch.Tensor, mask: Optional[torch.Tensor], s: float) -> torch.Tensor:
+    """bf16(lo * mask * s) as torch computes it left to right; a multiplication by exactly 1.0 changes no bit and is skipped
+    (alpha == r in both reference harnesses: one elementwise pass over [tokens, d] less per adapter and layer)."""
+    if mask is not None:
+        lo = lo * mask
+    if s != 1.0:
+        lo = lo * s
+    return lo.contiguous()
+
+
 class _DecoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model: GPT, idx: torch.Tensor, *lora_ps: torch.Tensor) -> torch.Tensor:
@@ -186,9 +196,7 @@ class _DecoderFn(torch.autograd.Function):
                 L.yd = L.mask2 = L.xa2 = None
                 L.x1 = ops.linear(L.y, proj_m.linear.weight.data, resid=x)
             L.n2 = ops.rmsnorm(L.x1, blk.norm_2.weight.data, cfg.norm_eps, row_tail=tail)
-            L.g = ops.linear(L.n2, blk.mlp.fc_1.linear.weight.data)
-            L.u = ops.linear(L.n2, blk.mlp.fc_2.linear.weight.data)
-            L.act = ops.swiglu_fwd(L.g, L.u)
+            L.act, L.g, L.u = ops.linear_swiglu_train(L.n2, blk.mlp.fc_1.linear.weight.data, blk.mlp.fc_2.linear.weight.data)
             x = ops.linear(L.act, blk.mlp.proj.linear.weight.data, resid=L.x1)
             saved.append(L)
         xf = ops.rmsnorm(x, model.transformer.ln_f.weight.data, cfg.norm_eps, row_tail=tail)
@@ -221,6 +229,7 @@ class _DecoderFn(torch.autograd.Function):
         dx = ops.rmsnorm_bwd(dxf, ctx.x_last, model.transformer.ln_f.weight.data, cfg.norm_eps)
         grads: List[Optional[torch.Tensor]] = []
         per_layer: List[List[Optional[torch.Tensor]]] = []
+        bwd_plan = ops.attn_bwd_plan(q_start, q_len, B * T, [T] * B)      # one set of index tensors for all layers
         for li in range(cfg.n_layer - 1, -1, -1):
             blk, L, W = model.transformer.h[li], ctx.saved[li], fz.layers[li]
             qkv_m, proj_m = blk.attn.attn, blk.attn.proj
@@ -239,7 +248,7 @@ class _DecoderFn(torch.autograd.Function):
                     dy = ops.linear(dx1, W["proj_T"], epilogue=ops.EPI_LORA, xa=t, lora_b=ApT, lora_scale=s)
                 else:
                     lo = ops.linear(_pad64(t), ApT64)
-                    dy = ops.linear(dx1, W["proj_T"], resid=(lo * L.mask2 * s).contiguous())
+                    dy = ops.linear(dx1, W["proj_T"], resid=_masked(lo, L.mask2, s))
                 gB2 = torch.empty((d, 16), dtype=torch.float32, device=dev)      # written whole (accumulate=False)
                 gA2 = torch.empty((16, d), dtype=torch.float32, device=dev)
                 ops.tn_accum(dx1, L.xa2, gB2, scale=s, accumulate=False)
@@ -247,7 +256,7 @@ class _DecoderFn(torch.autograd.Function):
             else:
                 dy = ops.linear(dx1, W["proj_T"])
             # ---- attention + rope
-            dq, dk, dv = ops.attn_bwd(L.q, L.k, L.v, L.y, dy, L.lse, q_start, q_len, T, lens=[T] * B)
+            dq, dk, dv = ops.attn_bwd(L.q, L.k, L.v, L.y, dy, L.lse, q_start, q_len, T, lens=[T] * B, plan=bwd_plan)
             dqkv = ops.qkv_rope_bwd(dq, dk, dv, cos, sin, tok_pos)
             # ---- fused qkv projection (+LoRA, contiguous [Q|K|V] delta placement, quirk Q2)
             gA1 = gB1 = None
@@ -259,8 +268,7 @@ class _DecoderFn(torch.autograd.Function):
                 bounds = (0, s0, s1, qd)
                 t3 = ops.linear(dqkv, Bblk)                              # [n,64], cols 16seg.. = dqkv[:,seg] · B_seg
                 lo = ops.linear(t3, A48T64)                              # [n,d] = t3 · A48
-                lo = lo * s if L.mask1 is None else lo * L.mask1 * s
-                dn1 = ops.linear(dqkv, W["qkv_T"], resid=lo.contiguous())
+                dn1 = ops.linear(dqkv, W["qkv_T"], resid=_masked(lo, L.mask1, s))
                 gB1 = torch.empty((qd, 16), dtype=torch.float32, device=dev)    # every segment written whole below
                 for seg in range(3):
                     ops.tn_accum(dqkv[:, bounds[seg]:bounds[seg + 1]], L.xa[:, 16 * seg:16 * seg + 16],

@@ -26,7 +26,7 @@ extern "C" {
 
 typedef uint16_t dh_bf16;
 
-#define DH_ABI_VERSION 5
+#define DH_ABI_VERSION 6
 
 int dh_abi_version(void);
 /* Kernel-variant selector for A/B measurements inside one process (bench.py --tune k=v); never needed in production,
@@ -213,6 +213,10 @@ int dh_dropout_bf16(const dh_bf16* x, dh_bf16* y, dh_bf16* mask, int64_t n, floa
                     const uint64_t* step_dev, void* stream);
 /* act = bf16(bf16(silu(g)) * u) from stored g, u (training forward keeps both; ger/model.py:315) */
 int dh_swiglu_fwd_bf16(const dh_bf16* g, const dh_bf16* u, dh_bf16* act, int64_t n, void* stream);
+/* Training forward of fc_1 / fc_2 in one launch (round 4, ABI 6): act = bf16(bf16(silu(g)) * u) with g = bf16(x.W1^T), u = bf16(x.W2^T)
+ * also stored ([M, I] each) for the backward — the bits of two dh_linear_bf16 launches + dh_swiglu_fwd_bf16 (ger/model.py:313-315). */
+int dh_linear_swiglu_train_bf16(const dh_bf16* x, const dh_bf16* w1, const dh_bf16* w2, dh_bf16* act,
+                                dh_bf16* g, dh_bf16* u, int M, int I, int K, void* stream);
 /* dgu[rows, 2I] = [dact*u*silu'(g) | dact*silu(g)]   (backward of ger/model.py:315) */
 int dh_swiglu_bwd_bf16(const dh_bf16* dact, const dh_bf16* g, const dh_bf16* u, dh_bf16* dgu, int rows,
                        int I, void* stream);
@@ -239,6 +243,10 @@ int dh_rowdot_f32(const dh_bf16* a, const dh_bf16* b, float* out, int64_t rows, 
 int dh_transpose_pad_bf16(const dh_bf16* src, dh_bf16* dst, const int32_t* tok_seq,
                           const int32_t* q_start, const int32_t* pad_start, int n_tok, int heads,
                           int hs, int n_pad, void* stream);
+/* The same copy from the INVERSE map (round 4, ABI 6): pad_tok[p] = token of padded position p, or -1 for padding (written as
+ * zeros: dst needs no memset).  16-byte accesses both ways; one block per padded 32-token tile and head.  src, dst 16-byte aligned. */
+int dh_transpose_frag_bf16(const dh_bf16* src, dh_bf16* dst, const int32_t* pad_tok, int heads, int hs,
+                           int n_pad, void* stream);
 /* Causal GQA attention backward (no KV cache; ger/model.py:287-289 under autograd): dq [n_tok,H,hs],
  * dk / dv [n_tok,G,hs] from q, k, v (rotated, plain), dout, lse (dh_attn_prefill_bf16) and
  * dsum = rowsum(dout*out); qT / doT / kT from dh_transpose_pad_bf16. */

@@ -24,7 +24,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/dualhyp_hip.h but not exported"
     assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
-    assert lib.dh_abi_version() == 5
+    assert lib.dh_abi_version() == 6
 
 
 def test_product_path_fails_loudly_without_gpu_tensors():

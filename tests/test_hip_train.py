@@ -680,3 +680,41 @@ def test_lora_dropout_kernel():
     # p = 0 keeps everything
     y0, m0 = ops.dropout(x, 0.0, seed=1, call_id=0, step=step)
     assert torch.equal(y0, x) and bool((m0 == 1).all())
+
+
+@pytest.mark.parametrize("M,I,K", [(1000, 5632, 512), (1024, 5600, 256), (40, 384, 256)])
+def test_swiglu_train_forward_is_the_three_launch_form(M, I, K):
+    """dh_linear_swiglu_train_bf16 (one GEMM launch that also stores fc_1(x), fc_2(x)) against linear, linear, swiglu_fwd: the same
+    bits, on full tiles, on a ragged M and column edge, and below the 256-tile kernel's range (where it IS the three launches)."""
+    from dualhyp_amd import ops
+    x, w1, w2 = U((M, K), 1.0, f"stx{M}").to(DEV), U((I, K), 0.08, f"stw1{I}").to(DEV), U((I, K), 0.08, f"stw2{I}").to(DEV)
+    act, g, u = ops.linear_swiglu_train(x, w1, w2)
+    g0, u0 = ops.linear(x, w1), ops.linear(x, w2)
+    assert torch.equal(g, g0) and torch.equal(u, u0)
+    assert torch.equal(act, ops.swiglu_fwd(g0, u0))
+    assert torch.equal(act, ops.linear(x, w1, epilogue=ops.EPI_SWIGLU, w2=w2))
+
+
+@pytest.mark.parametrize("hs,heads", [(64, 5), (128, 2)])
+def test_fragment_order_transpose_from_the_inverse_map(hs, heads):
+    """dh_transpose_frag_bf16 (16-byte accesses, inverse map, padding written as zeros) against dh_transpose_pad_bf16 into a zeroed
+    destination: the same bytes, sequences that end inside a 32-token tile included."""
+    from dualhyp_amd import ops, _lib
+    lib = _lib.load()
+    lens = [70, 33, 1, 128, 31]
+    n_tok = sum(lens)
+    i32 = torch.int32
+    src = U((n_tok, heads, hs), 1.0, f"tf{hs}").to(DEV)
+    starts = torch.tensor([sum(lens[:i]) for i in range(len(lens))], dtype=i32, device=DEV)
+    qlen = torch.tensor(lens, dtype=i32, device=DEV)
+    plan = ops.attn_bwd_plan(starts, qlen, n_tok, lens)
+    n_pad = plan["n_pad"]
+    assert n_pad == sum(-(-n // 32) * 32 for n in lens) and int((plan["pad_tok"] >= 0).sum()) == n_tok
+    tok_seq = torch.repeat_interleave(torch.arange(len(lens), dtype=i32, device=DEV), qlen.long())
+    want = torch.zeros((heads, hs, n_pad), dtype=torch.bfloat16, device=DEV)
+    ops.check(lib.dh_transpose_pad_bf16(src.data_ptr(), want.data_ptr(), tok_seq.data_ptr(), starts.data_ptr(), plan["pad_start"].data_ptr(),
+                                        n_tok, heads, hs, n_pad, torch.cuda.current_stream().cuda_stream))
+    got = torch.full((heads, hs, n_pad), 7.0, dtype=torch.bfloat16, device=DEV)
+    ops.check(lib.dh_transpose_frag_bf16(src.data_ptr(), got.data_ptr(), plan["pad_tok"].data_ptr(), heads, hs, n_pad,
+                                         torch.cuda.current_stream().cuda_stream))
+    assert torch.equal(got, want)
