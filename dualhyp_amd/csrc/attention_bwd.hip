@@ -17,6 +17,8 @@
 //       dQ^T[d][q] += K^T[d][key] . dS^T[key][q]    (A = kT fragment,  B = dS^T accumulator)
 #include "common.h"
 
+int g_attn_bwd_dq_group = 1;    // dh_set_tuning(27, 0): the single-wave dq kernel of rounds 2-3 (A/B)
+
 namespace {
 
 // Token-contiguous copies of q / dO / k for the products that take them TRANSPOSED, stored in MFMA-FRAGMENT ORDER (round 3; as the
@@ -382,6 +384,125 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(
     }
 }
 
+// Round 4: the dq kernel with one BLOCK per (query tile, group, sequence) and one wave per query head of the group.  The K, V and
+// K^T fragments of a key tile are the same for every head of the group: the single-wave kernel above fetches them once per head
+// (12 KiB per tile pair from L2: 2.1 GB per call on the packed micro-step, the kernel's bound), here each 1-KiB fragment goes
+// HBM/L2 -> LDS once per block by LDS-DMA, in fragment order (lane l's 16 bytes at l * 16: conflict-free ds_read_b128), double
+// buffered one key tile ahead.  The arithmetic per (head, query tile) is the single-wave kernel's, product for product.
+template <int HS>
+__global__ __launch_bounds__(512) void attn_bwd_dq_group_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+    const bf16_t* __restrict__ dout, const bf16_t* __restrict__ kT, const float* __restrict__ lse,
+    const float* __restrict__ dsum, const int32_t* __restrict__ q_start, const int32_t* __restrict__ q_len,
+    const int32_t* __restrict__ pad_start, bf16_t* __restrict__ dq, int n_head, int n_groups, int n_pad, float scale, int nt,
+    int n_seq) {
+    constexpr int KS = HS / 16, DT = HS / 32, NF = 2 * KS + 2 * DT;      // 1-KiB fragments per key tile: K, V (KS each), K^T (2 DT)
+    extern __shared__ __attribute__((aligned(16))) char dq_smem[];       // [2][NF][1 KiB]
+    int seq, g, qt;
+    {
+        // as the dkdv kernel: a (group, sequence) pair's query tiles share one XCD; the long tiles (large qt) first
+        const int np = n_groups * n_seq, b = blockIdx.x, j = b >> 3, pair = (b & 7) + 8 * (j / nt);
+        if (pair >= np) return;
+        qt = nt - 1 - j % nt; g = pair % n_groups; seq = pair / n_groups;
+    }
+    const int len = q_len[seq];
+    if (qt * 32 >= len) return;                                          // block-uniform, in front of every barrier
+    const int qs = q_start[seq], ps = pad_start[seq];
+    const int qpk = n_head / n_groups;                                   // = waves of the block
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lr = lane & 31, lh = lane >> 5;
+    const int head = g * qpk + wave;
+    const int q0 = qt * 32;
+    int qrow = q0 + lr;
+    const bool q_ok = qrow < len;
+    qrow = q_ok ? qrow : len - 1;
+    bf16x8 qf[KS], dof[KS];
+    {
+        const bf16_t* qp = q + ((size_t)(qs + qrow) * n_head + head) * HS + lh * 8;
+        const bf16_t* dop = dout + ((size_t)(qs + qrow) * n_head + head) * HS + lh * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+            dof[ks] = *reinterpret_cast<const bf16x8*>(dop + ks * 16);
+        }
+    }
+    const float l = lse[(size_t)(qs + qrow) * n_head + head];
+    const float dd = dsum[(size_t)(qs + qrow) * n_head + head];
+    const int q_abs = q0 + lr;
+    f32x16 dqT[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dqT[dt][r] = 0.f;
+    const int tile0 = ps >> 5;
+    // fragment f of key tile kt -> buffer b: K ks (f < KS), V ks (f < 2 KS), K^T (s2, dt); wave w moves f = w, w + qpk, ...
+    auto issue = [&](int kt, int b) __attribute__((always_inline)) {
+        int key = kt * 32 + lr;
+        key = key < len ? key : len - 1;
+        // (the asm form: behind the builtin the compiler waits vmcnt(0) in front of every LDS read that may alias the destination,
+        // i.e. for the NEXT tile's fragments before this tile's products; 32-bit byte offsets: the host checks the tensor sizes)
+        const uint32_t row_off = (uint32_t)((((size_t)(qs + key) * n_groups + g) * HS + lh * 8) * 2);
+        for (int f = wave; f < NF; f += qpk) {
+            char* dst = dq_smem + (b * NF + f) * 1024;
+            if (f < KS) glds16_saddr(k, row_off + (uint32_t)f * 32u, dst);
+            else if (f < 2 * KS) glds16_saddr(v, row_off + (uint32_t)(f - KS) * 32u, dst);
+            else glds16_saddr(kT, (uint32_t)(tfrag_lane<HS>(g, n_pad, tile0 + kt, (f - 2 * KS) / DT, (f - 2 * KS) % DT, lane) * 2), dst);
+        }
+    };
+    // the compiler cannot see the asm DMA in its vmcnt bookkeeping: left alone it waits for the loads above at their first use INSIDE
+    // the loop, with counts that also wait out the next tile's DMA.  Use them here, once: no compiler-visible load is pending in the loop.
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]), "+v"(dof[ks]));
+    asm volatile("" ::"v"(l), "v"(dd));
+    issue(0, 0);
+    for (int kt = 0; kt <= qt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                 // key tile kt is in LDS for every wave; every wave is done with the other buffer
+        if (kt < qt) issue(kt + 1, (kt + 1) & 1);
+        const char* buf = dq_smem + (kt & 1) * NF * 1024 + lane * 16;
+        const int key0 = kt * 32;
+        f32x16 st, dpt;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st[r] = 0.f; dpt[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(buf + ks * 1024);
+            const bf16x8 vf = *reinterpret_cast<const bf16x8*>(buf + (KS + ks) * 1024);
+            st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st, 0, 0, 0);        // rows key, cols q
+            dpt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[ks], dpt, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ka = key0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const bool ok = q_ok && ka < len && ka <= q_abs;
+            const float p = ok ? __expf(st[r] * scale - l) : 0.f;
+            st[r] = p * (dpt[r] - dd);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            union { bf16x8 v; uint32_t u[4]; } dsf;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dsf.u[j] = pack2bf(st[8 * s2 + 2 * j], st[8 * s2 + 2 * j + 1]);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(buf + (2 * KS + s2 * DT + dt) * 1024);
+                dqT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, dsf.v, dqT[dt], 0, 0, 0);   // [d][q]
+            }
+        }
+    }
+    if (q_ok) {
+        bf16_t* dst = dq + ((size_t)(qs + q0 + lr) * n_head + head) * HS;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int d = dt * 32 + 8 * rg + 4 * lh;
+                uint2 pk = make_uint2(pack2bf(dqT[dt][rg * 4 + 0] * scale, dqT[dt][rg * 4 + 1] * scale),
+                                      pack2bf(dqT[dt][rg * 4 + 2] * scale, dqT[dt][rg * 4 + 3] * scale));
+                *reinterpret_cast<uint2*>(dst + d) = pk;
+            }
+    }
+}
+
 }  // namespace
 
 extern "C" int dh_transpose_pad_bf16(const dh_bf16* src, dh_bf16* dst, const int32_t* tok_seq, const int32_t* q_start,
@@ -421,22 +542,33 @@ extern "C" int dh_attn_bwd_bf16(const dh_bf16* q, const dh_bf16* k, const dh_bf1
     const size_t lds = (size_t)(qpk < 4 ? qpk : 4) * 2 * (hs / 32) * 16 * 64 * sizeof(float);   // four waves at a time pass through LDS
     const int np_kv = n_groups * n_seq, np_q = n_head * n_seq;
     const int grid_kv = np_kv >= 8 ? 8 * cdiv(np_kv, 8) * nt : np_kv * nt, grid_q = 8 * cdiv(np_q, 8) * nt;
+    const int grid_qg = 8 * cdiv(np_kv, 8) * nt;        // the group form of the dq kernel: (group, sequence) pairs
+    // its LDS-DMA addresses K / V / K^T through 32-bit byte offsets
+    const bool dq_group = g_attn_bwd_dq_group && (size_t)n_pad * n_groups * hs * 2 < (1ull << 32);
     if (hs == 64) {
 #define DKDV(QT) do { DH_MAX_LDS_ONCE((attn_bwd_dkdv_kernel<64, QT>), 160 * 1024);                                       \
         hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, QT>), dim3(grid_kv), dim3(64 * qpk), lds, s, q, k, v, dout, qT, doT, lse, dsum,  \
                            q_start, q_len, pad_start, dk, dv, n_head, n_groups, n_pad, scale, nt, n_seq); } while (0)
         if (qpk == 8) DKDV(8); else if (qpk >= 4) DKDV(4); else DKDV(1);
 #undef DKDV
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), dim3(grid_q), dim3(64), 0, s, q, k, v, dout, kT, lse, dsum,
-                           q_start, q_len, pad_start, dq, n_head, n_groups, n_pad, scale, nt, n_seq);
+        if (dq_group)
+            hipLaunchKernelGGL((attn_bwd_dq_group_kernel<64>), dim3(grid_qg), dim3(64 * qpk), 2 * (2 * 4 + 2 * 2) * 1024, s, q, k, v, dout, kT, lse, dsum,
+                               q_start, q_len, pad_start, dq, n_head, n_groups, n_pad, scale, nt, n_seq);
+        else
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<64>), dim3(grid_q), dim3(64), 0, s, q, k, v, dout, kT, lse, dsum,
+                               q_start, q_len, pad_start, dq, n_head, n_groups, n_pad, scale, nt, n_seq);
     } else {
 #define DKDV(QT) do { DH_MAX_LDS_ONCE((attn_bwd_dkdv_kernel<128, QT>), 160 * 1024);                                       \
         hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128, QT>), dim3(grid_kv), dim3(64 * qpk), lds, s, q, k, v, dout, qT, doT, lse, dsum,  \
                            q_start, q_len, pad_start, dk, dv, n_head, n_groups, n_pad, scale, nt, n_seq); } while (0)
         if (qpk == 8) DKDV(8); else if (qpk >= 4) DKDV(4); else DKDV(1);
 #undef DKDV
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<128>), dim3(grid_q), dim3(64), 0, s, q, k, v, dout, kT, lse, dsum,
-                           q_start, q_len, pad_start, dq, n_head, n_groups, n_pad, scale, nt, n_seq);
+        if (dq_group)
+            hipLaunchKernelGGL((attn_bwd_dq_group_kernel<128>), dim3(grid_qg), dim3(64 * qpk), 2 * (2 * 8 + 2 * 4) * 1024, s, q, k, v, dout, kT, lse, dsum,
+                               q_start, q_len, pad_start, dq, n_head, n_groups, n_pad, scale, nt, n_seq);
+        else
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<128>), dim3(grid_q), dim3(64), 0, s, q, k, v, dout, kT, lse, dsum,
+                               q_start, q_len, pad_start, dq, n_head, n_groups, n_pad, scale, nt, n_seq);
     }
     DH_LAUNCH_CHECK();
     return 0;
