@@ -246,6 +246,7 @@ int launch(const GemmArgs& a, hipStream_t s) {
 }  // namespace
 
 int g_gemm_variant = 5;
+int g_tail_split = 1;     // dh_set_tuning(28, 0): no row split of grids with a small last round (A/B)
 int g_linear_phase = 0;   // kernel choice of the public dh_linear_bf16 (dh_set_tuning key 4; tools and tests)
 
 extern "C" int dh_linear_bf16(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N, int K, int epilogue,
@@ -381,6 +382,28 @@ int dh_linear_impl(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N,
     // the 256-tile kernel runs one block per CU: below ~half a chip of tiles (a training micro-batch, M ~ 560)
     // the 128-tile kernel puts four times the blocks in flight and wins
     const bool big = !skinny && dh_linear_is_big(M, N, epilogue);
+    // Wave quantisation (round 4): the 256-tile kernels run one tile per CU at a time, so a grid of R full rounds plus a FEW tiles
+    // costs R + 1 rounds (the packed fine-tune: 17 920 rows x 2048 columns = 560 tiles = 2.19 rounds -> 3).  When the remainder is
+    // under 0.3 of a round, the whole row tiles of the full rounds go to the 256-tile kernel and the remaining rows (a few hundred
+    // to a few thousand) to the 128-tile kernel, which puts four times the blocks in flight.  Same accumulator chain per output in
+    // both kernels (one accumulator, k ascending): the same bits as the single launch.
+    static thread_local bool in_split = false;
+    if (big && g_tail_split && !in_split && (epilogue == DH_EPI_PLAIN || epilogue == DH_EPI_LORA)) {
+        int dev = 0, cu = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu = 256;
+        const int nbn = cdiv(N, 256), tiles = cdiv(M, 256) * nbn, rounds = tiles / cu, rem = tiles % cu;
+        const int m1_tiles = rounds * cu / nbn, M1 = m1_tiles * 256, M2 = M - M1;
+        if (rounds >= 1 && rem > 0 && rem * 10 <= cu * 3 && M2 > 0 && M2 <= 4096 && dh_linear_is_big(M1, N, epilogue) &&
+            !dh_linear_is_big(M2, N, epilogue)) {
+            in_split = true;
+            int rc = dh_linear_impl(x, w, y, M1, N, K, epilogue, w2, xa, xa_ld, lora_b, lora_scale, split0, split1, vec_a, vec_b, resid, kernel, s);
+            if (rc == 0)
+                rc = dh_linear_impl(x + (size_t)M1 * K, w, y + (size_t)M1 * N, M2, N, K, epilogue, w2, xa ? xa + (size_t)M1 * xa_ld : nullptr, xa_ld,
+                                    lora_b, lora_scale, split0, split1, vec_a, vec_b, resid ? resid + (size_t)M1 * N : nullptr, kernel, s);
+            in_split = false;
+            return rc;
+        }
+    }
     if (big) {
         if (epilogue == DH_EPI_LORA) {
             DH_CHECK(xa && lora_b && xa_ld >= 16 && xa_ld % 8 == 0, "dh_linear_bf16: LORA epilogue needs xa/lora_b");

@@ -718,3 +718,23 @@ def test_fragment_order_transpose_from_the_inverse_map(hs, heads):
     ops.check(lib.dh_transpose_frag_bf16(src.data_ptr(), got.data_ptr(), plan["pad_tok"].data_ptr(), heads, hs, n_pad,
                                          torch.cuda.current_stream().cuda_stream))
     assert torch.equal(got, want)
+
+
+def test_row_split_of_a_grid_with_a_small_last_round_keeps_the_bits():
+    """dh_linear_bf16 on 17 920 x 2048 (560 tiles of 256 x 256 = 2.19 rounds of the chip): the rows of the two full rounds on the
+    256-tile kernel + the last 1 536 rows on the 128-tile kernel against the single launch (dh_set_tuning(28, 0)); plain, with a
+    residual, and with the LoRA epilogue (xa from memory)."""
+    from dualhyp_amd import ops, _lib
+    lib = _lib.load()
+    M, N, K = 32 * 560, 2048, 256
+    x, w, r = U((M, K), 1.0, "rsx").to(DEV), U((N, K), 0.08, "rsw").to(DEV), U((M, N), 1.0, "rsr").to(DEV)
+    xa, lb = U((M, 16), 1.0, "rsxa").to(DEV), U((N, 16), 0.1, "rslb").to(DEV)
+    cases = [dict(), dict(resid=r), dict(epilogue=ops.EPI_LORA, xa=xa, lora_b=lb, lora_scale=2.0, resid=r)]
+    try:
+        got = [ops.linear(x, w, **kw) for kw in cases]
+        lib.dh_set_tuning(28, 0)
+        want = [ops.linear(x, w, **kw) for kw in cases]
+    finally:
+        lib.dh_set_tuning(28, 1)
+    for g_, w_ in zip(got, want):
+        assert torch.equal(g_, w_)
