@@ -112,30 +112,42 @@ __global__ __launch_bounds__(256) void qkv_rope_bwd_kernel(const bf16_t* __restr
                                                            const bf16_t* __restrict__ dv, const bf16_t* __restrict__ cos,
                                                            const bf16_t* __restrict__ sin, const int32_t* __restrict__ tok_pos,
                                                            bf16_t* __restrict__ dqkv, int n_tok, int n_head, int n_groups) {
-    constexpr int HALF = HS / 2;
+    // one thread = 8 channels of the first half of a head and the matching 8 of the second half: 16-byte accesses throughout
+    // (round 4; the element-per-thread form moved 2 bytes per lane: 129 us per call on the packed micro-step, 1.4 TB/s)
+    constexpr int HALF = HS / 2, C8 = HALF / 8;
     const int q_per_kv = n_head / n_groups;
     const int heads = q_per_kv + 2;
     const int row_elems = n_groups * heads * HS;
-    const size_t total = (size_t)n_tok * n_groups * heads * HALF;
+    const size_t total = (size_t)n_tok * n_groups * heads * C8;
     for (size_t it = blockIdx.x * (size_t)blockDim.x + threadIdx.x; it < total; it += (size_t)gridDim.x * blockDim.x) {
-        const int i = (int)(it % HALF);
-        const int j = (int)((it / HALF) % heads);
-        const int g = (int)((it / ((size_t)HALF * heads)) % n_groups);
-        const int t = (int)(it / ((size_t)HALF * heads * n_groups));
+        const int i = (int)(it % C8) * 8;
+        const int j = (int)((it / C8) % heads);
+        const int g = (int)((it / ((size_t)C8 * heads)) % n_groups);
+        const int t = (int)(it / ((size_t)C8 * heads * n_groups));
         bf16_t* dst = dqkv + (size_t)t * row_elems + (g * heads + j) * HS;
         if (j == q_per_kv + 1) {                       // v: straight copy
             const bf16_t* s = dv + ((size_t)t * n_groups + g) * HS;
-            dst[i] = s[i];
-            dst[HALF + i] = s[HALF + i];
+            *reinterpret_cast<uint4*>(dst + i) = *reinterpret_cast<const uint4*>(s + i);
+            *reinterpret_cast<uint4*>(dst + HALF + i) = *reinterpret_cast<const uint4*>(s + HALF + i);
             continue;
         }
         const bf16_t* s = j < q_per_kv ? dq + ((size_t)t * n_head + g * q_per_kv + j) * HS : dk + ((size_t)t * n_groups + g) * HS;
         const int pos = tok_pos[t];
-        const float c1 = bf2f(cos[(size_t)pos * HS + i]), c2 = bf2f(cos[(size_t)pos * HS + HALF + i]);
-        const float s1 = bf2f(sin[(size_t)pos * HS + i]), s2 = bf2f(sin[(size_t)pos * HS + HALF + i]);
-        const float d1 = bf2f(s[i]), d2 = bf2f(s[HALF + i]);
-        dst[i] = f2bf(d1 * c1 + d2 * s2);
-        dst[HALF + i] = f2bf(d2 * c2 - d1 * s1);
+        const uint4 c1v = *reinterpret_cast<const uint4*>(cos + (size_t)pos * HS + i), c2v = *reinterpret_cast<const uint4*>(cos + (size_t)pos * HS + HALF + i);
+        const uint4 s1v = *reinterpret_cast<const uint4*>(sin + (size_t)pos * HS + i), s2v = *reinterpret_cast<const uint4*>(sin + (size_t)pos * HS + HALF + i);
+        const uint4 d1v = *reinterpret_cast<const uint4*>(s + i), d2v = *reinterpret_cast<const uint4*>(s + HALF + i);
+        const bf16_t *c1 = (const bf16_t*)&c1v, *c2 = (const bf16_t*)&c2v, *s1 = (const bf16_t*)&s1v, *s2 = (const bf16_t*)&s2v;
+        const bf16_t *d1 = (const bf16_t*)&d1v, *d2 = (const bf16_t*)&d2v;
+        uint4 o1, o2;
+        bf16_t *o1p = (bf16_t*)&o1, *o2p = (bf16_t*)&o2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float a = bf2f(d1[e]), b = bf2f(d2[e]);
+            o1p[e] = f2bf(a * bf2f(c1[e]) + b * bf2f(s2[e]));
+            o2p[e] = f2bf(b * bf2f(c2[e]) - a * bf2f(s1[e]));
+        }
+        *reinterpret_cast<uint4*>(dst + i) = o1;
+        *reinterpret_cast<uint4*>(dst + HALF + i) = o2;
     }
 }
 

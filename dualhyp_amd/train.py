@@ -103,7 +103,7 @@ def prepare_for_training(model: GPT) -> List[torch.nn.Parameter]:
 
 
 class _Layer:
-    __slots__ = ("x", "n1", "n1d", "xa", "q", "k", "v", "y", "lse", "xa2", "yd", "x1", "n2", "g", "u", "act", "mask1", "mask2")
+    __slots__ = ("x", "n1", "n1d", "xa", "q", "k", "v", "y", "lse", "xa2", "yd", "x1", "n2", "g", "u", "act", "mask1", "mask2", "vq", "vp")
 
 
 def _drop(x: torch.Tensor, p: float, training: bool, model=None, call_id: int = 0):
@@ -173,7 +173,8 @@ class _DecoderFn(torch.autograd.Function):
             L.x = x
             L.n1 = ops.rmsnorm(x, blk.norm_1.weight.data, cfg.norm_eps, row_tail=tail)
             if qkv_m.lora_active:
-                A48, B16 = _lora_views(qkv_m, True)[:2]
+                L.vq = _lora_views(qkv_m, True)          # kept for the backward of the same micro-step (same weights)
+                A48, B16 = L.vq[:2]
                 L.n1d, L.mask1 = _drop(L.n1, p_drop, training, model, 2 * len(saved))
                 L.xa = ops.linear(L.n1d, A48)
                 qkv = ops.linear(L.n1, qkv_m.linear.weight.data, epilogue=ops.EPI_LORA, xa=L.xa, lora_b=B16,
@@ -187,7 +188,8 @@ class _DecoderFn(torch.autograd.Function):
             L.lse = torch.empty((n_tok, H), dtype=torch.float32, device=dev)
             L.y = ops.attn_prefill(L.q, kc, vt, seq_slot, q_start, q_len, zeros, T, lse=L.lse)
             if proj_m.lora_active:
-                Ap, Bp = _lora_views(proj_m, False)[:2]
+                L.vp = _lora_views(proj_m, False)
+                Ap, Bp = L.vp[:2]
                 L.yd, L.mask2 = _drop(L.y, p_drop, training, model, 2 * len(saved) + 1)
                 L.xa2 = ops.linear(L.yd, Ap)
                 L.x1 = ops.linear(L.y, proj_m.linear.weight.data, epilogue=ops.EPI_LORA, xa=L.xa2, lora_b=Bp,
@@ -242,7 +244,7 @@ class _DecoderFn(torch.autograd.Function):
             gA2 = gB2 = None
             if proj_m.lora_active:
                 s = proj_m.scaling
-                Ap, Bp, ApT, BpT, ApT64 = _lora_views(proj_m, False)    # [16,d], [d,16] and transposes
+                Ap, Bp, ApT, BpT, ApT64 = L.vp                          # [16,d], [d,16] and transposes (built by the forward)
                 t = ops.linear(dx1, BpT)                                # dx1 · Bp           [n,16]
                 if L.mask2 is None:
                     dy = ops.linear(dx1, W["proj_T"], epilogue=ops.EPI_LORA, xa=t, lora_b=ApT, lora_scale=s)
@@ -262,7 +264,7 @@ class _DecoderFn(torch.autograd.Function):
             gA1 = gB1 = None
             if qkv_m.lora_active:
                 s = qkv_m.scaling
-                A48, B16, _, _, Bblk, A48T64 = _lora_views(qkv_m, True)  # [48,d], [qkv,16], block B^T [64,qkv], A^T [d,64]
+                A48, B16, _, _, Bblk, A48T64 = L.vq                      # [48,d], [qkv,16], block B^T [64,qkv], A^T [d,64]
                 qd = B16.size(0)
                 s0, s1 = qkv_m.splits
                 bounds = (0, s0, s1, qd)
