@@ -63,6 +63,7 @@ SIGNATURES = {
     "dh_rowdot_f32": (I, [P, P, P, I64, I, P]),
     "dh_transpose_pad_bf16": (I, [P, P, P, P, P, I, I, I, I, P]),
     "dh_transpose_frag_bf16": (I, [P, P, P, I, I, I, P]),
+    "dh_attn_bwd_transposes": (I, [I, I, I, I]),
     "dh_attn_bwd_bf16": (I, [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P]),
     "dh_attn_decode_work_bytes": (I64, [I, I, I, I]),
     "dh_attn_decode_bf16": (I, [P, P, P, P, P, P, P, I, I, I, I, I, P]),

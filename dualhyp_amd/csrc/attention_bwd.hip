@@ -17,6 +17,7 @@
 //       dQ^T[d][q] += K^T[d][key] . dS^T[key][q]    (A = kT fragment,  B = dS^T accumulator)
 #include "common.h"
 
+int g_attn_bwd_dkdv_img = 1;    // dh_set_tuning(29, 0): the dkdv kernel with every operand fetched from global memory per wave (A/B)
 int g_attn_bwd_dq_group = 1;    // dh_set_tuning(27, 0): the single-wave dq kernel of rounds 2-3 (A/B)
 
 namespace {
@@ -98,7 +99,13 @@ __global__ __launch_bounds__(256) void transpose_frag_kernel(const bf16_t* __res
     }
 }
 
-template <int HS, int QPKT>   // QPKT <= query heads per group (block = 64 x that many threads): sizes the per-thread totals
+// IMG (round 4, hs 64): a wave's q / dO tile goes HBM/L2 -> LDS ONCE by LDS-DMA (a private double-buffered 2 x 8 KiB image per wave) and
+// serves BOTH operand shapes — row fragments by ds_read_b128, transposed fragments by ds_read_b64_tr_b16 (cdna_hip_programming.md T10) —
+// instead of 8 KiB of row loads plus 8 KiB of the transposed copies qT / doT per tile pair (the kernel's bound: 2.8 GB per call from
+// L2 on the packed micro-step); qT / doT are then not read at all.  Image of a tile: 4 pieces of 1 KiB = 8 rows x 128 B, 16-byte chunk c of
+// row r of a piece at (8 c + r) * 16: a DMA piece is one whole-line request per row, a row fragment is 8 consecutive lanes on 128 B,
+// the four rows of a transposed read sit in 64 consecutive bytes.  Same products in the same order: the bits of the register form.
+template <int HS, int QPKT, bool IMG = false>   // QPKT <= query heads per group (block = 64 x that many threads): sizes the per-thread totals
 __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ dout, const bf16_t* __restrict__ qT, const bf16_t* __restrict__ doT,
@@ -159,8 +166,26 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(
     // requested at the top of iteration qt, the transposed pieces of tile qt before its first MFMA: by the time they are
     // needed one whole phase of MFMAs and exps has passed.  lse / D travel as ONE value per lane (row q0 + lane % 32) and
     // reach the accumulator layout's rows through ds_bpermute instead of 16 loads per lane each.
-    constexpr bool PIPE = HS == 64;       // hs 128 doubles every fragment set: the second set of row operands would spill
+    static_assert(!IMG || HS == 64, "the LDS image form is sized for hs 64 (16 KiB per wave)");
+    constexpr bool PIPE = HS == 64 && !IMG;       // hs 128 doubles every fragment set: the second set of row operands would spill
     struct RowOps { bf16x8 qf[KS], dof[KS]; float l, d; };
+    char* img = reinterpret_cast<char*>(red) + (IMG ? __builtin_amdgcn_readfirstlane(wave) * 16384 : 0);   // IMG: [2][q 4 KiB | dO 4 KiB] of this wave
+    auto load_ld = [&](RowOps& R, int qt) __attribute__((always_inline)) {
+        int qrow = qt * 32 + lr;
+        qrow = qrow < len ? qrow : len - 1;
+        R.l = lse[(size_t)(qs + qrow) * n_head + head];
+        R.d = dsum[(size_t)(qs + qrow) * n_head + head];
+    };
+    auto issue_tile = [&](int qt, int b) __attribute__((always_inline)) {      // IMG: the 2 x 4 pieces of tile qt -> buffer b
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) {
+            int qrow = qt * 32 + 8 * pc + (lane & 7);
+            qrow = qrow < len ? qrow : len - 1;
+            const uint32_t off = (uint32_t)((((size_t)(qs + qrow) * n_head + head) * HS + (lane >> 3) * 8) * 2);
+            glds16_saddr(q, off, img + b * 8192 + pc * 1024);
+            glds16_saddr(dout, off, img + b * 8192 + 4096 + pc * 1024);
+        }
+    };
     auto load_rows = [&](RowOps& R, int qt) __attribute__((always_inline)) {
         int qrow = qt * 32 + lr;
         qrow = qrow < len ? qrow : len - 1;
@@ -171,13 +196,37 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(
             R.qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
             R.dof[ks] = *reinterpret_cast<const bf16x8*>(dop + ks * 16);
         }
-        R.l = lse[(size_t)(qs + qrow) * n_head + head];
-        R.d = dsum[(size_t)(qs + qrow) * n_head + head];
+        load_ld(R, qt);
     };
     RowOps cur, nxt;
-    load_rows(cur, kt);
+    if constexpr (IMG) {
+        // (the compiler does not count the asm DMA: the K / V fragments are used here once, so that no load of its own is pending when
+        // the loop's counted waits begin — see attn_bwd_dq_group_kernel)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(kf[ks]), "+v"(vf[ks]));
+        load_ld(cur, kt);
+        issue_tile(kt, 0);
+    } else {
+        load_rows(cur, kt);
+    }
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     for (int qt = kt; qt < n_qt; ++qt) {
         const int q0 = qt * 32;
+        const char* tile = img + ((qt - kt) & 1) * 8192;
+        if constexpr (IMG) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // tile qt (and its lse / D) has landed; nothing else is in flight
+            if (qt + 1 < n_qt) {                                         // wave-uniform
+                load_ld(nxt, qt + 1);
+                issue_tile(qt + 1, (qt + 1 - kt) & 1);                   // (the other buffer's last reads fed iteration qt - 1's MFMAs)
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const char* rp = tile + (lr >> 3) * 1024 + ((2 * ks + lh) * 8 + (lr & 7)) * 16;
+                cur.qf[ks] = *reinterpret_cast<const bf16x8*>(rp);
+                cur.dof[ks] = *reinterpret_cast<const bf16x8*>(rp + 4096);
+            }
+        }
         // transposed pieces of THIS tile (A operands of the dV / dK products), requested before the S / dP products
         union TP { bf16x8 v; uint2 h[2]; };
         TP af[2][DT], bfr[2][DT];
@@ -189,6 +238,21 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(
                 bfr[s2][dt].v = *reinterpret_cast<const bf16x8*>(qT + fo);
             }
         };
+        auto load_tr_img = [&](int s2) __attribute__((always_inline)) {  // lane 4 qq + p of a 16-lane group: row qq, columns 4 p ..; receives column i
+            const int g16 = lane >> 4, qq = (lane >> 2) & 3, p = lane & 3;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int c = 4 * dt + 2 * (g16 & 1) + (p >> 1), r = 4 * (g16 >> 1) + qq;      // chunk, row inside the 8-row piece
+                const char* rp = tile + (2 * s2) * 1024 + (c * 8 + r) * 16 + 8 * (p & 1);
+                const s16x4 qa = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)rp);
+                const s16x4 qb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(rp + 1024));
+                const s16x4 da = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(rp + 4096));
+                const s16x4 db = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(rp + 4096 + 1024));
+                bfr[s2][dt].v = bf16x8{qa[0], qa[1], qa[2], qa[3], qb[0], qb[1], qb[2], qb[3]};
+                af[s2][dt].v = bf16x8{da[0], da[1], da[2], da[3], db[0], db[1], db[2], db[3]};
+            }
+        };
+        if (IMG) load_tr_img(0);
         if (PIPE) load_tr(0);
         if (PIPE && qt + 1 < n_qt) load_rows(nxt, qt + 1);       // wave-uniform
         f32x16 s, dp;
@@ -200,6 +264,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(
             dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.dof[ks], vf[ks], dp, 0, 0, 0);
         }
         if (PIPE) load_tr(1);                            // lands under the exps below
+        if (IMG) load_tr_img(1);
         // P and dS in the accumulator layout: row (q) = (r&3) + 8*(r>>2) + 4*lh, col (key) = lr
         const int key_abs = key0 + lr;
 #pragma unroll
@@ -223,7 +288,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(
             }
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                if (!PIPE) {                               // hs 128: one fragment pair at a time (8 registers live)
+                if (!PIPE && !IMG) {                       // hs 128: one fragment pair at a time (8 registers live)
                     const size_t fo = tfrag_lane<HS>(head, n_pad, tile0 + qt, s2, dt, lane);
                     af[s2][dt].v = *reinterpret_cast<const bf16x8*>(doT + fo);
                     bfr[s2][dt].v = *reinterpret_cast<const bf16x8*>(qT + fo);
@@ -233,10 +298,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_kernel(
             }
         }
         if (qt + 1 < n_qt) {
-            if (PIPE) cur = nxt;
+            if (IMG) { cur.l = nxt.l; cur.d = nxt.d; }
+            else if (PIPE) cur = nxt;
             else load_rows(cur, qt + 1);
         }
     }
+    if constexpr (IMG) __syncthreads();           // the reduction below reuses the waves' images
     // ---- sum the heads of the group (LDS), then write dK (scaled) and dV: lane col = key, rows = d.  The waves pass
     // through LDS FOUR at a time (64 KiB at hs 64 instead of 128: two blocks per CU, twice the waves to hide the loop's
     // global-load latency); the sum still runs over the heads in index order (w0 + w1 + ... from zero).
@@ -526,12 +593,20 @@ extern "C" int dh_transpose_frag_bf16(const dh_bf16* src, dh_bf16* dst, const in
     return 0;
 }
 
+// which transposed copies dh_attn_bwd_bf16 reads for this shape: bit 0 = qT and doT, bit 1 = kT (the rest may be passed as null)
+extern "C" int dh_attn_bwd_transposes(int n_head, int n_groups, int hs, int n_pad) {
+    (void)n_groups;
+    const bool dkdv_img = g_attn_bwd_dkdv_img && hs == 64 && (size_t)n_pad * n_head * hs * 2 < (1ull << 32);
+    return (dkdv_img ? 0 : 1) | 2;
+}
+
 extern "C" int dh_attn_bwd_bf16(const dh_bf16* q, const dh_bf16* k, const dh_bf16* v, const dh_bf16* dout,
                                 const dh_bf16* qT, const dh_bf16* doT, const dh_bf16* kT, const float* lse,
                                 const float* dsum, const int32_t* q_start, const int32_t* q_len, const int32_t* pad_start,
                                 dh_bf16* dq, dh_bf16* dk, dh_bf16* dv, int n_seq, int max_q_len, int n_head, int n_groups,
                                 int hs, int n_pad, void* stream) {
-    DH_CHECK(q && k && v && dout && qT && doT && kT && lse && dsum && dq && dk && dv, "dh_attn_bwd_bf16: null argument");
+    DH_CHECK(q && k && v && dout && kT && lse && dsum && dq && dk && dv, "dh_attn_bwd_bf16: null argument");
+    DH_CHECK((qT && doT) || !(dh_attn_bwd_transposes(n_head, n_groups, hs, n_pad) & 1), "dh_attn_bwd_bf16: this shape reads qT / doT (dh_attn_bwd_transposes)");
     DH_CHECK(hs == 64 || hs == 128, "dh_attn_bwd_bf16: head_size %d unsupported", hs);
     DH_CHECK(n_groups > 0 && n_head % n_groups == 0 && n_head / n_groups <= 8, "dh_attn_bwd_bf16: at most 8 query heads per group");
     DH_CHECK(n_pad % 32 == 0, "dh_attn_bwd_bf16: n_pad must be a multiple of 32");
@@ -543,13 +618,17 @@ extern "C" int dh_attn_bwd_bf16(const dh_bf16* q, const dh_bf16* k, const dh_bf1
     const int np_kv = n_groups * n_seq, np_q = n_head * n_seq;
     const int grid_kv = np_kv >= 8 ? 8 * cdiv(np_kv, 8) * nt : np_kv * nt, grid_q = 8 * cdiv(np_q, 8) * nt;
     const int grid_qg = 8 * cdiv(np_kv, 8) * nt;        // the group form of the dq kernel: (group, sequence) pairs
+    // the image form of the dkdv kernel (hs 64): 16 KiB per wave, q / dO addressed through 32-bit byte offsets
+    const size_t lds_img = std::max(lds, (size_t)qpk * 16384);
+    const bool dkdv_img = g_attn_bwd_dkdv_img && hs == 64 && (size_t)n_pad * n_head * hs * 2 < (1ull << 32);
     // its LDS-DMA addresses K / V / K^T through 32-bit byte offsets
     const bool dq_group = g_attn_bwd_dq_group && (size_t)n_pad * n_groups * hs * 2 < (1ull << 32);
     if (hs == 64) {
-#define DKDV(QT) do { DH_MAX_LDS_ONCE((attn_bwd_dkdv_kernel<64, QT>), 160 * 1024);                                       \
-        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, QT>), dim3(grid_kv), dim3(64 * qpk), lds, s, q, k, v, dout, qT, doT, lse, dsum,  \
+#define DKDV(QT, IM) do { DH_MAX_LDS_ONCE((attn_bwd_dkdv_kernel<64, QT, IM>), 160 * 1024);                                       \
+        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<64, QT, IM>), dim3(grid_kv), dim3(64 * qpk), IM ? lds_img : lds, s, q, k, v, dout, qT, doT, lse, dsum,  \
                            q_start, q_len, pad_start, dk, dv, n_head, n_groups, n_pad, scale, nt, n_seq); } while (0)
-        if (qpk == 8) DKDV(8); else if (qpk >= 4) DKDV(4); else DKDV(1);
+        if (dkdv_img) { if (qpk == 8) DKDV(8, true); else if (qpk >= 4) DKDV(4, true); else DKDV(1, true); }
+        else { if (qpk == 8) DKDV(8, false); else if (qpk >= 4) DKDV(4, false); else DKDV(1, false); }
 #undef DKDV
         if (dq_group)
             hipLaunchKernelGGL((attn_bwd_dq_group_kernel<64>), dim3(grid_qg), dim3(64 * qpk), 2 * (2 * 4 + 2 * 2) * 1024, s, q, k, v, dout, kT, lse, dsum,

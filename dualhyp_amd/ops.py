@@ -525,7 +525,9 @@ def attn_bwd(q, k, v, out, dout, lse, q_start, q_len, max_q_len: int, lens: Opti
         dst = torch.empty((heads, hs, n_pad), dtype=torch.bfloat16, device=dev)      # padding is written (zeros) by the kernel
         check(lib.dh_transpose_frag_bf16(keep(src), _p(dst), _p(pad_tok), heads, hs, n_pad, _stream()))
         return dst
-    qT, doT, kT = tpad(q, H), tpad(dout, H), tpad(k, G)
+    need = lib.dh_attn_bwd_transposes(H, G, hs, n_pad)      # hs 64: the dk/dv kernel transposes its q / dO tiles in LDS
+    qT, doT = (tpad(q, H), tpad(dout, H)) if need & 1 else (None, None)
+    kT = tpad(k, G)
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     check(lib.dh_attn_bwd_bf16(keep(q, name="q"), keep(k, name="k"), keep(v, name="v"), _p(dout), _p(qT), _p(doT), _p(kT), _p(lse), _p(dsum), _p(q_start),
                                _p(q_len), _p(pad_start), _p(dq), _p(dk), _p(dv), plan["n_seq"], int(max_q_len), H, G, hs,

@@ -249,7 +249,10 @@ int dh_transpose_frag_bf16(const dh_bf16* src, dh_bf16* dst, const int32_t* pad_
                            int n_pad, void* stream);
 /* Causal GQA attention backward (no KV cache; ger/model.py:287-289 under autograd): dq [n_tok,H,hs],
  * dk / dv [n_tok,G,hs] from q, k, v (rotated, plain), dout, lse (dh_attn_prefill_bf16) and
- * dsum = rowsum(dout*out); qT / doT / kT from dh_transpose_pad_bf16. */
+ * dsum = rowsum(dout*out); qT / doT / kT from dh_transpose_pad_bf16 / dh_transpose_frag_bf16 (those dh_attn_bwd_transposes names). */
+/* Which transposed copies dh_attn_bwd_bf16 reads for a shape (round 4, ABI 6): bit 0 = qT and doT, bit 1 = kT; the others may be null.
+ * (hs 64: the dk/dv kernel stages q / dO tiles in LDS and reads them transposed there — ds_read_b64_tr_b16 — so only kT is needed.) */
+int dh_attn_bwd_transposes(int n_head, int n_groups, int hs, int n_pad);
 int dh_attn_bwd_bf16(const dh_bf16* q, const dh_bf16* k, const dh_bf16* v, const dh_bf16* dout,
                      const dh_bf16* qT, const dh_bf16* doT, const dh_bf16* kT, const float* lse,
                      const float* dsum, const int32_t* q_start, const int32_t* q_len,

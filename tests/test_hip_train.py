@@ -127,6 +127,17 @@ def test_rope_and_attention_bwd(hs, n_head, n_groups):
     y = ops.attn_prefill(q, kc, vt, torch.arange(B, dtype=i32, device=DEV), starts, qlen, torch.zeros(B, dtype=i32, device=DEV),
                          max(lens), lse=lse)
     dq, dk, dv = ops.attn_bwd(q, k_out, v_out, y, dout.to(DEV), lse, starts, qlen, max(lens))
+    # round 4's kernels (dq: one block per group with K / V / K^T staged in LDS; dkdv at hs 64: q / dO tiles through an LDS image with
+    # transposed reads) run the same products in the same order as the per-wave kernels of rounds 2-3: the same bits
+    from dualhyp_amd import _lib
+    try:
+        _lib.load().dh_set_tuning(27, 0)
+        _lib.load().dh_set_tuning(29, 0)
+        dq0, dk0, dv0 = ops.attn_bwd(q, k_out, v_out, y, dout.to(DEV), lse, starts, qlen, max(lens))
+    finally:
+        _lib.load().dh_set_tuning(27, 1)
+        _lib.load().dh_set_tuning(29, 1)
+    assert torch.equal(dq, dq0) and torch.equal(dk, dk0) and torch.equal(dv, dv0)
     dqkv = ops.qkv_rope_bwd(dq, dk, dv, cos.to(DEV), sin.to(DEV), pos)
     # reference: fp32 autograd through split + rope + SDPA, per sequence
     t0 = 0
