@@ -60,6 +60,7 @@ SIGNATURES = {
     "dh_qkv_rope_bwd_bf16": (I, [P, P, P, P, P, P, P, I, I, I, I, P]),
     "dh_tn_accum_f32": (I, [P, I, P, I, P, I, I, I, I, F, I, P, P]),
     "dh_tn_accum_work_bytes": (I64, [I, I, I]),
+    "dh_tn_accum_seg_f32": (I, [P, I, P, I, P, I, I, I, I, I, F, I, P, P]),
     "dh_rowdot_f32": (I, [P, P, P, I64, I, P]),
     "dh_transpose_pad_bf16": (I, [P, P, P, P, P, I, I, I, I, P]),
     "dh_transpose_frag_bf16": (I, [P, P, P, I, I, I, P]),

@@ -23,6 +23,7 @@
 // to the instruction's K = 32) lacc = lora_B[16 n,16] · xa[16 m,16]^T, and
 // y = bf16(bf16(acc) + bf16(bf16(lacc)*s)).
 #include "common.h"
+#include <atomic>
 #include "gemm.h"
 
 int g_gemm128_stages = 0;   // 0: by grid size, else 2 or 4 (dh_set_tuning key 9)
@@ -389,8 +390,13 @@ int dh_linear_impl(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N,
     // both kernels (one accumulator, k ascending): the same bits as the single launch.
     static thread_local bool in_split = false;
     if (big && g_tail_split && !in_split && (epilogue == DH_EPI_PLAIN || epilogue == DH_EPI_LORA)) {
-        int dev = 0, cu = 256;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cu = 256;
+        static std::atomic<int> n_cu{0};                 // (one device model per process: replicas of the same GPU)
+        int cu = n_cu.load(std::memory_order_relaxed);
+        if (cu == 0) {
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256;
+            n_cu.store(cu, std::memory_order_relaxed);
+        }
         const int nbn = cdiv(N, 256), tiles = cdiv(M, 256) * nbn, rounds = tiles / cu, rem = tiles % cu;
         const int m1_tiles = rounds * cu / nbn, M1 = m1_tiles * 256, M2 = M - M1;
         if (rounds >= 1 && rem > 0 && rem * 10 <= cu * 3 && M2 > 0 && M2 <= 4096 && dh_linear_is_big(M1, N, epilogue) &&

@@ -3,6 +3,7 @@
 // attention backward (attention_bwd.hip).  Activations and activation-gradients are bf16, sums are
 // fp32, LoRA gradients are accumulated in fp32 buffers.
 #include "common.h"
+#include <climits>
 
 int g_tn_mfma = 1;    // dh_set_tuning(26, 0): the LoRA-gradient contraction on the VALU kernel of rounds 2-3 (A/B)
 
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(1024) void tn_accum_wide_kernel(const bf16_t* __res
 template <bool LARGE_IS_M, int SB>
 __global__ __launch_bounds__(256, 2) void tn_accum_mfma_kernel(const bf16_t* __restrict__ a, int lda, const bf16_t* __restrict__ b,
                                                                int ldb, float* __restrict__ out, int ldo, int T, int M, int N,
-                                                               float scale, int accumulate, int tchunk) {
+                                                               float scale, int accumulate, int tchunk, int seg0, int seg1) {
     if (gridDim.z > 1) {
         const int t_begin = blockIdx.z * tchunk;
         a += (size_t)t_begin * lda;
@@ -284,7 +285,9 @@ __global__ __launch_bounds__(256, 2) void tn_accum_mfma_kernel(const bf16_t* __r
     const bf16_t* small = LARGE_IS_M ? b : a;
     const int ldbig = LARGE_IS_M ? lda : ldb, ldsm = LARGE_IS_M ? ldb : lda;
     const int L = LARGE_IS_M ? M : N;
-    const int l0 = blockIdx.x * LC, s0 = blockIdx.y * 16 * SB;
+    // seg0 / seg1 (dh_tn_accum_seg_f32; multiples of 128, INT_MAX = unused): the LARGE dimension is cut into up to three segments and
+    // segment i contracts with columns 16 i .. of the small operand (the three LoRA-B gradients of the fused QKV projection in one launch)
+    const int l0 = blockIdx.x * LC, s0 = blockIdx.y * 16 * SB + 16 * ((l0 >= seg0) + (l0 >= seg1));
     // ---- DMA sources.  large piece pi of a stage: tokens 4 pi + (lane & 3), 16-byte chunk lane >> 2 of the block's 256 bytes (clamped
     // to the row's last chunk: L % 8 == 0); wave w moves pieces 4 w .. 4 w + 3.  small piece sp: image sp >> 1, tokens 32 (sp & 1) + lane / 2.
     const int colc = min(l0 + 8 * (lane >> 2), L - 8);
@@ -372,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void tn_accum_mfma_kernel(const bf16_t* __r
         for (int sb = 0; sb < SB; ++sb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int s = s0 + 16 * sb + 4 * kg + r;
+                const int s = blockIdx.y * 16 * SB + 16 * sb + 4 * kg + r;      // (output index: without the segment's column offset)
                 float* o = LARGE_IS_M ? out + (size_t)l * ldo + s : out + (size_t)s * ldo + l;
                 *o = (accumulate ? *o : 0.f) + scale * acc[j][sb][r];
             }
@@ -513,8 +516,8 @@ extern "C" int64_t dh_tn_accum_work_bytes(int T, int M, int N) {
     return T > 2 * TN_CHUNK ? (int64_t)cdiv(T, TN_CHUNK) * M * N * (int64_t)sizeof(float) : 0;
 }
 
-extern "C" int dh_tn_accum_f32(const dh_bf16* a, int lda, const dh_bf16* b, int ldb, float* out, int ldo, int T, int M,
-                               int N, float scale, int accumulate, void* work, void* stream) {
+static int tn_accum_impl(const dh_bf16* a, int lda, const dh_bf16* b, int ldb, float* out, int ldo, int T, int M,
+                         int N, float scale, int accumulate, void* work, void* stream, int seg0, int seg1) {
     DH_CHECK(a && b && out && T >= 0 && M > 0 && N > 0, "dh_tn_accum_f32: bad argument");
     hipStream_t st = (hipStream_t)stream;
     // the small operand is read as aligned 16-byte runs
@@ -528,22 +531,25 @@ extern "C" int dh_tn_accum_f32(const dh_bf16* a, int lda, const dh_bf16* b, int 
         const bf16_t* big = n_small ? a : b;
         const int ldbig = n_small ? lda : ldb, L = n_small ? M : N, S = n_small ? N : M, ldsm = n_small ? ldb : lda;
         const int t_span = nz > 1 ? TN_CHUNK : T;
-        const bool mfma = g_tn_mfma && T > 0 && L % 8 == 0 && ldbig % 8 == 0 && ((uintptr_t)big & 15) == 0 &&
+        const bool segmented = seg0 != INT_MAX || seg1 != INT_MAX;
+        DH_CHECK(!segmented || (n_small && N == 16), "dh_tn_accum_seg_f32: segments need a large M and N == 16");
+        const bool mfma = (g_tn_mfma || segmented) && T > 0 && L % 8 == 0 && ldbig % 8 == 0 && ((uintptr_t)big & 15) == 0 &&
                           (size_t)t_span * ldbig * 2 < (1ull << 32) && (size_t)t_span * ldsm * 2 < (1ull << 32);
+        DH_CHECK(mfma || !segmented, "dh_tn_accum_seg_f32: operands must be 16-byte aligned with row strides that are multiples of 8");
         if (mfma) {
             const int sb = S == 48 ? 3 : 1;
             const dim3 grid(cdiv(L, 128), S / (16 * sb), nz), block(256);
             const int lds1 = 3 * (64 * 128 * 2 + 64 * 32), lds3 = 3 * (64 * 128 * 2 + 64 * 32 * 3);
             if (n_small && sb == 1) {
-                hipLaunchKernelGGL((tn_accum_mfma_kernel<true, 1>), grid, block, lds1, st, a, lda, b, ldb, dst, ldo, T, M, N, scale, accumulate, TN_CHUNK);
+                hipLaunchKernelGGL((tn_accum_mfma_kernel<true, 1>), grid, block, lds1, st, a, lda, b, ldb, dst, ldo, T, M, N, scale, accumulate, TN_CHUNK, seg0, seg1);
             } else if (n_small) {
                 DH_MAX_LDS_ONCE((tn_accum_mfma_kernel<true, 3>), lds3);
-                hipLaunchKernelGGL((tn_accum_mfma_kernel<true, 3>), grid, block, lds3, st, a, lda, b, ldb, dst, ldo, T, M, N, scale, accumulate, TN_CHUNK);
+                hipLaunchKernelGGL((tn_accum_mfma_kernel<true, 3>), grid, block, lds3, st, a, lda, b, ldb, dst, ldo, T, M, N, scale, accumulate, TN_CHUNK, seg0, seg1);
             } else if (sb == 1) {
-                hipLaunchKernelGGL((tn_accum_mfma_kernel<false, 1>), grid, block, lds1, st, a, lda, b, ldb, dst, ldo, T, M, N, scale, accumulate, TN_CHUNK);
+                hipLaunchKernelGGL((tn_accum_mfma_kernel<false, 1>), grid, block, lds1, st, a, lda, b, ldb, dst, ldo, T, M, N, scale, accumulate, TN_CHUNK, seg0, seg1);
             } else {
                 DH_MAX_LDS_ONCE((tn_accum_mfma_kernel<false, 3>), lds3);
-                hipLaunchKernelGGL((tn_accum_mfma_kernel<false, 3>), grid, block, lds3, st, a, lda, b, ldb, dst, ldo, T, M, N, scale, accumulate, TN_CHUNK);
+                hipLaunchKernelGGL((tn_accum_mfma_kernel<false, 3>), grid, block, lds3, st, a, lda, b, ldb, dst, ldo, T, M, N, scale, accumulate, TN_CHUNK, seg0, seg1);
             }
         } else if (n_small)
             hipLaunchKernelGGL((tn_accum_wide_kernel<true, 1>), dim3(cdiv(M, 64), N / 16, nz), dim3(1024), 0, st, a, lda, b, ldb, dst, ldo,
@@ -561,6 +567,21 @@ extern "C" int dh_tn_accum_f32(const dh_bf16* a, int lda, const dh_bf16* b, int 
                        ldo, T, M, N, scale, accumulate);
     DH_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int dh_tn_accum_f32(const dh_bf16* a, int lda, const dh_bf16* b, int ldb, float* out, int ldo, int T, int M,
+                               int N, float scale, int accumulate, void* work, void* stream) {
+    return tn_accum_impl(a, lda, b, ldb, out, ldo, T, M, N, scale, accumulate, work, stream, INT_MAX, INT_MAX);
+}
+
+// out[m][n] (+)= scale * sum_t a[t][m] * b[t][16 seg(m) + n], n < 16, seg(m) = (m >= seg0) + (m >= seg1): the LoRA-B gradients of the
+// three segments of a fused QKV projection (ger/lora.py:367-402: q, k and v have their own rank-16 pair) in ONE launch over the
+// projection's output gradient instead of one per segment.  seg0 <= seg1, multiples of 128.
+extern "C" int dh_tn_accum_seg_f32(const dh_bf16* a, int lda, const dh_bf16* b, int ldb, float* out, int ldo, int T, int M,
+                                   int seg0, int seg1, float scale, int accumulate, void* work, void* stream) {
+    DH_CHECK(seg0 >= 0 && seg0 <= seg1 && seg0 % 128 == 0 && seg1 % 128 == 0, "dh_tn_accum_seg_f32: segment starts must be ordered multiples of 128");
+    DH_CHECK(ldb >= 48, "dh_tn_accum_seg_f32: b holds 3 x 16 columns");
+    return tn_accum_impl(a, lda, b, ldb, out, ldo, T, M, 16, scale, accumulate, work, stream, seg0, seg1);
 }
 
 extern "C" int dh_rowdot_f32(const dh_bf16* a, const dh_bf16* b, float* out, int64_t rows, int hs, void* stream) {

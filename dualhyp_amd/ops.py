@@ -475,14 +475,20 @@ def qkv_rope_bwd(dq: torch.Tensor, dk: torch.Tensor, dv: torch.Tensor, cos: torc
     return out
 
 
-def tn_accum(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, scale: float = 1.0, accumulate: bool = True) -> None:
-    """out[M,N] (+)= scale * a[T,M].T @ b[T,N]; a/b may be column slices of wider row-major matrices."""
+def tn_accum(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, scale: float = 1.0, accumulate: bool = True,
+             splits: Optional[Tuple[int, int]] = None) -> None:
+    """out[M,N] (+)= scale * a[T,M].T @ b[T,N]; a/b may be column slices of wider row-major matrices.
+    splits = (s0, s1): out[M,16], rows m of segment seg(m) = (m >= s0) + (m >= s1) contract with b[:, 16 seg : 16 seg + 16]."""
     assert a.stride(1) == 1 and b.stride(1) == 1 and out.dtype == torch.float32 and out.stride(1) == 1
     T, M = a.shape
-    N = b.size(1)
+    N = b.size(1) if splits is None else 16
     lib = _lib.load()
     wb = lib.dh_tn_accum_work_bytes(T, M, N)       # packed micro-batches: the token loop is split over the grid
     work = torch.empty(wb // 4, dtype=torch.float32, device=a.device) if wb else None
+    if splits is not None:
+        check(lib.dh_tn_accum_seg_f32(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0),
+                                      T, M, int(splits[0]), int(splits[1]), float(scale), int(accumulate), _p(work), _stream()))
+        return
     check(lib.dh_tn_accum_f32(a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0),
                               T, M, N, float(scale), int(accumulate), _p(work), _stream()))
 

@@ -272,9 +272,12 @@ class _DecoderFn(torch.autograd.Function):
                 lo = ops.linear(t3, A48T64)                              # [n,d] = t3 · A48
                 dn1 = ops.linear(dqkv, W["qkv_T"], resid=_masked(lo, L.mask1, s))
                 gB1 = torch.empty((qd, 16), dtype=torch.float32, device=dev)    # every segment written whole below
-                for seg in range(3):
-                    ops.tn_accum(dqkv[:, bounds[seg]:bounds[seg + 1]], L.xa[:, 16 * seg:16 * seg + 16],
-                                 gB1[bounds[seg]:bounds[seg + 1]], scale=s, accumulate=False)
+                if s0 % 128 == 0 and s1 % 128 == 0 and dqkv.size(0) >= 64:
+                    ops.tn_accum(dqkv, L.xa, gB1, scale=s, accumulate=False, splits=(s0, s1))      # the three segments in one launch
+                else:
+                    for seg in range(3):
+                        ops.tn_accum(dqkv[:, bounds[seg]:bounds[seg + 1]], L.xa[:, 16 * seg:16 * seg + 16],
+                                     gB1[bounds[seg]:bounds[seg + 1]], scale=s, accumulate=False)
                 gA1 = torch.empty((48, d), dtype=torch.float32, device=dev)
                 ops.tn_accum(t3[:, :48], L.n1d, gA1, scale=s, accumulate=False)
             else:

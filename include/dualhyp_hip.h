@@ -234,6 +234,11 @@ int dh_qkv_rope_bwd_bf16(const dh_bf16* dq, const dh_bf16* dk, const dh_bf16* dv
 int64_t dh_tn_accum_work_bytes(int T, int M, int N);
 int dh_tn_accum_f32(const dh_bf16* a, int lda, const dh_bf16* b, int ldb, float* out, int ldo, int T,
                     int M, int N, float scale, int accumulate, void* work, void* stream);
+/* The same contraction for the three LoRA-B gradients of a fused QKV projection in one launch (round 4, ABI 6):
+ * out[m][n] (+)= scale * sum_t a[t][m] * b[t][16 seg(m) + n], n < 16, seg(m) = (m >= seg0) + (m >= seg1); seg0 <= seg1 multiples of 128,
+ * b [T, >= 48]; work as dh_tn_accum_work_bytes(T, M, 16). */
+int dh_tn_accum_seg_f32(const dh_bf16* a, int lda, const dh_bf16* b, int ldb, float* out, int ldo, int T,
+                        int M, int seg0, int seg1, float scale, int accumulate, void* work, void* stream);
 /* out[row] = sum_d a[row,d]*b[row,d]   (softmax-backward row term D = rowsum(dO*O)) */
 int dh_rowdot_f32(const dh_bf16* a, const dh_bf16* b, float* out, int64_t rows, int hs, void* stream);
 /* src [n_tok, heads, hs] -> dst (heads * hs * n_pad elements, zero-initialised by the caller): the token-contiguous copy the

@@ -749,3 +749,21 @@ def test_row_split_of_a_grid_with_a_small_last_round_keeps_the_bits():
         lib.dh_set_tuning(28, 1)
     for g_, w_ in zip(got, want):
         assert torch.equal(g_, w_)
+
+
+@pytest.mark.parametrize("T", [300, 4480])
+def test_segmented_token_contraction_is_the_three_calls(T):
+    """dh_tn_accum_seg_f32 (the three LoRA-B gradients of a fused QKV projection in one launch) against one dh_tn_accum_f32 per
+    segment: the same kernel and chains, the same bits; and torch fp32."""
+    from dualhyp_amd import ops
+    qd, s0, s1 = 640, 384, 512
+    a, b = U((T, qd), 1.0, f"sga{T}").to(DEV), U((T, 48), 1.0, f"sgb{T}").to(DEV)
+    got = torch.empty((qd, 16), dtype=torch.float32, device=DEV)
+    ops.tn_accum(a, b, got, scale=0.5, accumulate=False, splits=(s0, s1))
+    want = torch.empty_like(got)
+    bounds = (0, s0, s1, qd)
+    for seg in range(3):
+        ops.tn_accum(a[:, bounds[seg]:bounds[seg + 1]], b[:, 16 * seg:16 * seg + 16], want[bounds[seg]:bounds[seg + 1]], scale=0.5, accumulate=False)
+    assert torch.equal(got, want)
+    ref = torch.cat([0.5 * a[:, bounds[i]:bounds[i + 1]].float().T @ b[:, 16 * i:16 * i + 16].float() for i in range(3)])
+    assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-4
