@@ -28,7 +28,8 @@
 #include "common.h"
 #include "gemm.h"
 
-int g_w4_fast_epi = 3;  // dh_set_tuning(24, bits): bit 0 the fused-QKV epilogue of full tiles in its v_dot2_f32_bf16 form (g256_epilogue_qkv_fast), bit 1 the same arithmetic in the LoRA / residual epilogues; 0 = the round-3 forms (A/B)
+int g_w4_fast_epi = 7;  // dh_set_tuning(24, bits): bit 0 the fused-QKV epilogue of full tiles in its v_dot2_f32_bf16 form (g256_epilogue_qkv_fast), bit 1 the same arithmetic in the LoRA / residual epilogues; bit 2: a persistent block's tile start leaves the previous FULL tile's last stores in flight (counted wait); 0 = the round-3 forms (A/B)
+int g_w4_persist_lora = 1;  // dh_set_tuning(30, 0 | 1): persistent blocks for the LoRA GEMM with the in-GEMM down-projection (attn proj of the prefill)
 int g_w4_persist_qkv = 0;   // dh_set_tuning(25, 0 | 1): persistent blocks for the fused-QKV GEMM with the in-GEMM LoRA.  OFF: measured 374-384 us per launch
                             // against 373-374 per-tile (same box, round 4): the tile loop keeps the K loop's invariants live across the epilogue (45 spilled registers)
 int g_w4_persist = 1;   // dh_set_tuning(22, 0 | 1 | 2): the 4-wave kernel walks the tiles with one block per CU: never / where the epilogue loads nothing / always
@@ -133,9 +134,12 @@ __device__ __forceinline__ uint2 rope_half(uint32_t ax, uint32_t ay, uint32_t bx
 // the first store, i.e. for the operands of every strip requested ahead.
 // XS: the wave's x.A^T fragments come from an LDS image [256 rows of the block tile][16 bf16] (the 4-wave kernel's in-GEMM LoRA
 // down-projection) instead of from the global xa tensor; the block tile then lies in ONE LoRA segment.
-template <int EPI, bool RESID, int MJ, bool FULL, bool XS = false>
+struct G256NoHook { __device__ __forceinline__ void operator()() const {} };
+// hook: called once, right behind the LAST batch of operand loads the epilogue issues (strip MJ - PD): a persistent block requests its
+// next tile's first stages there — younger than every load the epilogue still waits for, with PD - 1 strips of work left to cover them
+template <int EPI, bool RESID, int MJ, bool FULL, bool XS = false, class Hook = G256NoHook>
 __device__ __forceinline__ void g256_epilogue(const GemmArgs& a, f32x4 (&acc)[8][MJ], const int m0, const int n0, const int wn,
-                                              const int wm, const int lane, const char* xs = nullptr) {
+                                              const int wm, const int lane, const char* xs = nullptr, Hook hook = Hook{}) {
     // SWIGLU with the RESID flag set is the TRAINING forward (dh_linear_swiglu_train_bf16): no residual is read; the epilogue also
     // stores the rounded pre-activations g = bf16(acc1) -> a.q_out and u = bf16(acc2) -> a.k_cache ([M, N] like y) that the backward needs
     constexpr bool GU = EPI == DH_EPI_SWIGLU && RESID;
@@ -258,6 +262,7 @@ __device__ __forceinline__ void g256_epilogue(const GemmArgs& a, f32x4 (&acc)[8]
         const int m = mw0 + j * 16 + frow;
         const bool m_ok = FULL || m < a.M;
         if constexpr (j + PD - 1 < MJ) load_strip(j + PD - 1, xfv2[(j + PD - 1) % PD], rrv2[(j + PD - 1) % PD]);
+        if constexpr (j == MJ - PD) hook();
         bf16x8 (&xfv)[LORA ? NT / 2 : 1] = xfv2[j % PD];
         uint4 (&rrv)[RES ? NT / 2 : 1] = rrv2[j % PD];
         if constexpr (EPI == DH_EPI_QKV && j + 1 < MJ) load_rope(j + 1, ropev[(j + 1) & 1]);
@@ -1110,10 +1115,17 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
     };
     setup_src(m0, n0);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    auto dma = [&](int d, int st, int b) __attribute__((always_inline)) {      // piece d (0..15: A0 B0 A1 B1 ...) of stage st -> buffer b
+    // vis: through the builtin, which the compiler COUNTS (vmcnt) — the form for requests issued in the middle of an epilogue whose own
+    // loads and stores the compiler is still counting (an asm request it cannot see makes every later counted wait also wait the DMA out);
+    // its price — a vmcnt(0) in front of every LDS read that may alias the destination — is paid nowhere: no LDS read follows in that epilogue
+    auto dma = [&](int d, int st, int b, auto vis_c) __attribute__((always_inline)) {      // piece d (0..15: A0 B0 A1 B1 ...) of stage st -> buffer b
+        constexpr bool VIS = decltype(vis_c)::value;
         const int j = d >> 1, R = wave_u * 8 + j;
         char* dst = smem + b * BUF + R * 1024;
-        auto issue = [&](const char* base, uint32_t vo, char* lds_dst) __attribute__((always_inline)) { glds16_saddr(base, vo, lds_dst); };   // common.h
+        auto issue = [&](const char* base, uint32_t vo, char* lds_dst) __attribute__((always_inline)) {
+            if constexpr (VIS) glds16(base + vo, lds_dst);
+            else glds16_saddr(base, vo, lds_dst);   // common.h
+        };
         if (d == 16) {
             issue(reinterpret_cast<const char*>(la_seg) + (size_t)st * 128, voX, smem + b * BUF + 2 * OPB + (wave_u & 1) * 1024);
         } else if (d & 1) {
@@ -1143,6 +1155,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
     };
     const int nst = a.K / 64;                         // >= 2 (dh_linear_256 checks)
     bf16x8 fa0[8], fb0[8], fa1[8], fb1[8];
+    constexpr std::true_type T{};
+    constexpr std::false_type F{};
     auto iteration = [&](auto pre_c, auto nxt_c, int st) __attribute__((always_inline)) {
         constexpr bool PRE = decltype(pre_c)::value, NXT = decltype(nxt_c)::value;
         const int b = st & 1;
@@ -1176,7 +1190,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
-            if constexpr (PRE && w4_dma_at(g, NP) >= 0) dma(w4_dma_at(g, NP), st + 2, b);
+            if constexpr (PRE && w4_dma_at(g, NP) >= 0) dma(w4_dma_at(g, NP), st + 2, b, F);
             if constexpr (NXT && g == DH_W4_B2) {
                 // the pieces of stage s+2 issued so far stay in flight; everything older (stage s+1) has landed
                 if constexpr (PRE) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(w4_dma_before(DH_W4_B2, NP)) : "memory");
@@ -1187,19 +1201,18 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
                 rd((g - DH_W4_RD0) / DH_W4_RD0STEP, b ^ 1, 0, fa0, fb0);
         });
     };
-    constexpr std::true_type T{};
-    constexpr std::false_type F{};
-    auto first_stages = [&]() __attribute__((always_inline)) {
+    auto first_stages = [&](auto vis_c) __attribute__((always_inline)) {
 #pragma unroll
-        for (int d = 0; d < NP; ++d) dma(d, 0, 0);
+        for (int d = 0; d < NP; ++d) dma(d, 0, 0, vis_c);
 #pragma unroll
-        for (int d = 0; d < NP; ++d) dma(d, 1, 1);
+        for (int d = 0; d < NP; ++d) dma(d, 1, 1, vis_c);
     };
-    first_stages();
+    first_stages(F);
     const int nwg = a.nb_n * a.nb_m;
     // PERSIST: the grid is one block per CU and a block walks tiles bid, bid + grid, ...; the first two stages of the NEXT tile are
     // requested before the epilogue of the current one, so the epilogue, its store drain, the block dispatch and the first stage's
     // latency overlap (the tile's K loop is only K / 64 = 32 iterations at K = 2048)
+    bool prev_full = false;
     for (int vb = blockIdx.x, first = 1;; first = 0) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -1209,8 +1222,18 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
 #pragma unroll
             for (int jx = 0; jx < 4; ++jx) xacc[jx] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        // first tile: stage 1 stays in flight; later tiles: the previous epilogue's stores share the counter with the loads
+        // first tile: stage 1 stays in flight.  Later tiles: the previous epilogue's stores share the counter with the loads, and the
+        // ones issued BEHIND this tile's first-stage requests are the youngest operations in flight — a FULL tile's epilogue issues a
+        // known number of them (one 16-byte store per column-tile pair and strip, unconditional), so the wait leaves exactly those in
+        // flight instead of waiting out the write acknowledgements of the last strips (vmcnt(0)); ragged tiles and the fused-QKV epilogue
+        // (stores that depend on the data) wait for everything
+        constexpr bool GU_ = EPI == DH_EPI_SWIGLU && RESID;
+        constexpr bool LATE_ = (XA && (EPI == DH_EPI_QKV || EPI == DH_EPI_LORA)) || (!XA && EPI == DH_EPI_PLAIN && RESID);
+        constexpr int STORES_PER_STRIP = EPI == DH_EPI_SWIGLU ? (GU_ ? 6 : 2) : 4;
+        constexpr int YOUNGER_STORES = EPI == DH_EPI_QKV ? 0 : (LATE_ ? 4 : 8) * STORES_PER_STRIP;      // late: the hook sits in front of strip 4's stores
+        static_assert(YOUNGER_STORES <= 63, "vmcnt field");
         if (!PERSIST || first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+        else if (prev_full && (a.fast_epi & 4)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER_STORES) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         G256_STAMP(1);
@@ -1249,20 +1272,23 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
         const int vb_next = vb + (int)gridDim.x;
         const bool more = PERSIST && vb_next < nwg;
         int m0n = 0, n0n = 0;
-        constexpr bool LATE_DMA = EPI == DH_EPI_QKV && XA;     // requested from inside the epilogue (its hook)
+        // requested from inside the epilogue (its hook): the epilogues that load — LoRA with the in-GEMM down-projection, plain + residual
+        constexpr bool LATE_DMA = (XA && (EPI == DH_EPI_QKV || EPI == DH_EPI_LORA)) || (!XA && EPI == DH_EPI_PLAIN && RESID);
+        constexpr bool VIS_DMA = EPI != DH_EPI_QKV;            // ... through the counted builtin where no LDS read follows in the epilogue
+        if constexpr (LATE_DMA && PERSIST && !XA) __builtin_amdgcn_s_barrier();    // every wave has read its last fragments (XA: the barrier behind the image)
         if (more) {
             g256_tile_origin<EPI>(a, vb_next, m0n, n0n);
             if constexpr (!LATE_DMA) {
                 __builtin_amdgcn_s_barrier();        // every wave has read its last fragments: both buffers are free
                 setup_src(m0n, n0n);
-                first_stages();
+                first_stages(F);
             }
         }
         // (XA kernels: the barrier behind the x.A^T image above already stands between every wave's last fragment read and this point)
         auto next_tile_dma = [&]() __attribute__((always_inline)) {
             if (more) {
                 setup_src(m0n, n0n);                 // (recomputed behind the epilogue: kept live across its last strips the 17 offsets spill)
-                first_stages();
+                first_stages(std::integral_constant<bool, VIS_DMA>{});
             }
         };
         G256_STAMP(2);
@@ -1279,11 +1305,17 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
                 else g256_epilogue_qkv_fast<128, false>(a, acc, m0, n0, wn, wm, lane, xs_img, vimg, next_tile_dma);
             }
         } else {
-            if (full) g256_epilogue<EPI, RESID, 8, true, XA>(a, acc, m0, n0, wn, wm, lane, xs_img);
-            else g256_epilogue<EPI, RESID, 8, false, XA>(a, acc, m0, n0, wn, wm, lane, xs_img);
+            if constexpr (LATE_DMA && PERSIST) {
+                if (full) g256_epilogue<EPI, RESID, 8, true, XA>(a, acc, m0, n0, wn, wm, lane, xs_img, next_tile_dma);
+                else g256_epilogue<EPI, RESID, 8, false, XA>(a, acc, m0, n0, wn, wm, lane, xs_img, next_tile_dma);
+            } else {
+                if (full) g256_epilogue<EPI, RESID, 8, true, XA>(a, acc, m0, n0, wn, wm, lane, xs_img);
+                else g256_epilogue<EPI, RESID, 8, false, XA>(a, acc, m0, n0, wn, wm, lane, xs_img);
+            }
         }
         G256_STAMP(3);
         if (!more) break;
+        prev_full = full;
         vb = vb_next;
         m0 = m0n;
         n0 = n0n;
@@ -1339,9 +1371,11 @@ int launch_w4(const GemmArgs& a, hipStream_t s) {
         if (a.lora_a != nullptr) return g_w4_persist_qkv ? launch_w4p<EPI, RESID, true, true>(a, s) : launch_w4p<EPI, RESID, false, true>(a, s);
     }
     if constexpr (EPI == DH_EPI_LORA) {
-        if (a.lora_a != nullptr) return launch_w4p<EPI, RESID, false, true>(a, s);      // w4_xa_ok checked by the caller
+        // w4_xa_ok checked by the caller.  Persistent form (round 4): the epilogue's hook requests the next tile's stages through the counted builtin
+        if (a.lora_a != nullptr) return g_w4_persist_lora ? launch_w4p<EPI, RESID, true, true>(a, s) : launch_w4p<EPI, RESID, false, true>(a, s);
     }
-    const bool persist = g_w4_persist == 2 || (g_w4_persist == 1 && ((!RESID && EPI == DH_EPI_PLAIN) || EPI == DH_EPI_SWIGLU));
+    const bool persist = g_w4_persist == 2 || (g_w4_persist == 1 && ((!RESID && EPI == DH_EPI_PLAIN) || EPI == DH_EPI_SWIGLU)) ||
+                         (g_w4_persist_lora && RESID && EPI == DH_EPI_PLAIN);
     return persist ? launch_w4p<EPI, RESID, true>(a, s) : launch_w4p<EPI, RESID, false>(a, s);
 }
 

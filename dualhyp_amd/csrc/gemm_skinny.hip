@@ -569,6 +569,7 @@ extern "C" int dh_set_tuning(int key, int value) {
     if (key == 24) { extern int g_w4_fast_epi; g_w4_fast_epi = value; return 0; }
     if (key == 25) { extern int g_w4_persist_qkv; g_w4_persist_qkv = value != 0; return 0; }
     if (key == 26) { extern int g_tn_mfma; g_tn_mfma = value != 0; return 0; }
+    if (key == 30) { extern int g_w4_persist_lora; g_w4_persist_lora = value != 0; return 0; }
     if (key == 29) { extern int g_attn_bwd_dkdv_img; g_attn_bwd_dkdv_img = value != 0; return 0; }
     if (key == 28) { extern int g_tail_split; g_tail_split = value != 0; return 0; }
     if (key == 27) { extern int g_attn_bwd_dq_group; g_attn_bwd_dq_group = value != 0; return 0; }
