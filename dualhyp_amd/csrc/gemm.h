@@ -37,6 +37,9 @@ constexpr int DH_EPI_QKV = 4;   // internal: LoRA (optional) + rope + cache appe
 
 // M <= 32: one pass over W straight from HBM to registers (gemm_skinny.hip)
 int dh_linear_skinny(const GemmArgs& a, int epilogue, hipStream_t s);
+// y[M, N] = bf16(x . W^T), N = 16 .. 64, thousands of rows (gemm_skinny.hip: gemm_skinny_n_kernel); the bits of the tiled kernels
+bool dh_linear_skinny_n_ok(int M, int N, int K, const void* x, const void* w, const void* y);
+int dh_linear_skinny_n(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N, int K, hipStream_t s);
 // the in-GEMM LoRA down-projection can run for these arguments (4-wave 256-tile kernel, tile-aligned segments): gemm256.hip
 bool dh_linear_256_xa_ok(const GemmArgs& a, int epilogue);
 

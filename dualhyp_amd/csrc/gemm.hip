@@ -379,6 +379,8 @@ int dh_linear_impl(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N,
     if ((kernel == 2 || (kernel == 0 && M <= 32)) && (epilogue != DH_EPI_SWIGLU || (w2 != nullptr && resid == nullptr)) &&
         (epilogue != DH_EPI_ADAPTER || (vec_a && vec_b)) && dh_linear_mid_ok(a, epilogue))
         return dh_linear_mid(a, epilogue, s);
+    if (kernel == 0 && epilogue == DH_EPI_PLAIN && resid == nullptr && dh_linear_skinny_n_ok(M, N, K, x, w, y))
+        return dh_linear_skinny_n(x, w, y, M, N, K, s);          // a LoRA down-projection of a long batch: 16-64 output columns
     const bool skinny = (kernel == 0 || kernel == 2) && M <= 32 && K % 32 == 0;   // weight-streaming kernel (gemm_skinny.hip)
     // the 256-tile kernel runs one block per CU: below ~half a chip of tiles (a training micro-batch, M ~ 560)
     // the 128-tile kernel puts four times the blocks in flight and wins

@@ -474,6 +474,81 @@ int launch(const GemmArgs& a, hipStream_t s) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------- skinny-N GEMM (round 4)
+// y[M, N] = bf16(x[M, K] . W[N, K]^T) for N = 16 .. 64 and M in the thousands: the LoRA down-projections of the fine-tune (x . A^T on the
+// dropped-out input, dy . B for the backward) read 73-92 MB to produce 16-64 columns.  On the 128-tile kernel they are one column
+// tile of mostly idle MFMA columns at 1.9-2.4 TB/s (30 us per call on the packed micro-step); here a block owns 64 rows, x and W go
+// HBM/L2 -> LDS in whole 128-byte lines by LDS-DMA (four 64-deep stages, three in flight; source-side XOR swizzle so the fragment
+// reads are conflict-free), and each wave multiplies its 16 rows against all of W.  One accumulator per output, k ascending in steps
+// of 32 on v_mfma_f32_16x16x32_bf16: the bits of the tiled kernels.
+template <int NT>
+__global__ __launch_bounds__(256, 2) void gemm_skinny_n_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                               bf16_t* __restrict__ y, int M, int K, int ldy) {
+    constexpr int RB = 64, NST = 4, XB = RB * 128, WB = NT * 16 * 128, STAGE = XB + WB;
+    constexpr int WPW = (2 * NT + 3) / 4, NPW = 2 + WPW;          // W pieces / all pieces per wave and stage (every wave the same number)
+    extern __shared__ __attribute__((aligned(16))) char sn_smem[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m0 = blockIdx.x * RB;
+    // ---- DMA sources: a piece = 8 rows x 128 B; LDS position P = lane & 7 of row r holds chunk P ^ ((r >> 1) & 7)
+    uint32_t xo[2], wo[WPW];
+    int wp[WPW];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = 8 * (2 * wave + i) + (lane >> 3);
+        const int row = min(m0 + r, M - 1);
+        xo[i] = ((uint32_t)row * (uint32_t)K + (uint32_t)(((lane & 7) ^ ((r >> 1) & 7)) * 8)) * 2u;
+    }
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) {
+        wp[i] = min(wave + 4 * i, 2 * NT - 1);                    // (a repeated piece writes the same bytes to the same place)
+        const int r = 8 * wp[i] + (lane >> 3);
+        wo[i] = ((uint32_t)r * (uint32_t)K + (uint32_t)(((lane & 7) ^ ((r >> 1) & 7)) * 8)) * 2u;
+    }
+    auto issue = [&](int st) __attribute__((always_inline)) {
+        char* base = sn_smem + (st % NST) * STAGE;
+        const bf16_t* xs = x + (size_t)st * 64;
+        const bf16_t* ws = w + (size_t)st * 64;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16_saddr(xs, xo[i], base + (2 * wave + i) * 1024);
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) glds16_saddr(ws, wo[i], base + XB + wp[i] * 1024);
+    };
+    const int nst = K / 64;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, kg = lane >> 4;
+    const int xr = 16 * wave + frow;                               // this lane's x row inside the block
+#pragma unroll 1
+    for (int st = 0; st < NST - 1 && st < nst; ++st) issue(st);
+#pragma unroll 1
+    for (int st = 0; st < nst; ++st) {
+        if (st + NST - 2 < nst) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * NPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                           // stage st has landed for every wave; every wave is done with stage st - 1
+        if (st + NST - 1 < nst) issue(st + NST - 1);
+        const char* base = sn_smem + (st % NST) * STAGE;
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            const int c = 4 * kh + kg;
+            const bf16x8 bf = *reinterpret_cast<const bf16x8*>(base + xr * 128 + ((c ^ ((xr >> 1) & 7)) << 4));
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int wr = 16 * t + frow;
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(base + XB + wr * 128 + ((c ^ ((wr >> 1) & 7)) << 4));
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // D[n = 16 t + 4 kg + r][m = row xr]
+    const int m = m0 + xr;
+    if (m < M) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            *reinterpret_cast<uint2*>(y + (size_t)m * ldy + 16 * t + 4 * kg) = make_uint2(pack2bf(acc[t][0], acc[t][1]), pack2bf(acc[t][2], acc[t][3]));
+    }
+}
+
 }  // namespace
 
 extern "C" int dh_linear_partial_bf16(const dh_bf16* x, const dh_bf16* w, const dh_bf16* w_ext, float* y32, int M,
@@ -541,6 +616,24 @@ extern "C" int dh_linear_chain_bf16(const dh_bf16* x, const dh_bf16* w, const dh
     return dh_chain_tiled(x, w, w_ext, y32, M, n_main, n_ext, K, kps, (hipStream_t)stream);
 }
 
+int g_skinny_n = 1;      // dh_set_tuning(31, 0): the 128-tile kernel for N <= 64 (A/B)
+bool dh_linear_skinny_n_ok(int M, int N, int K, const void* x, const void* w, const void* y) {
+    return g_skinny_n && N >= 16 && N <= 64 && N % 16 == 0 && M >= 512 && K >= 64 && K % 64 == 0 && (size_t)M * K * 2 < (1ull << 32) &&
+           (((uintptr_t)x | (uintptr_t)w) & 15) == 0 && ((uintptr_t)y & 7) == 0;
+}
+int dh_linear_skinny_n(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N, int K, hipStream_t s) {
+    const dim3 grid(cdiv(M, 64)), block(256);
+    const int nt = N / 16, lds = 4 * (64 * 128 + nt * 16 * 128);
+    switch (nt) {
+        case 1: hipLaunchKernelGGL((gemm_skinny_n_kernel<1>), grid, block, lds, s, x, w, y, M, K, N); break;
+        case 2: hipLaunchKernelGGL((gemm_skinny_n_kernel<2>), grid, block, lds, s, x, w, y, M, K, N); break;
+        case 3: hipLaunchKernelGGL((gemm_skinny_n_kernel<3>), grid, block, lds, s, x, w, y, M, K, N); break;
+        default: hipLaunchKernelGGL((gemm_skinny_n_kernel<4>), grid, block, lds, s, x, w, y, M, K, N); break;
+    }
+    DH_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int dh_set_tuning(int key, int value) {
     if (key == 0) { g_skinny_variant = value; return 0; }
     if (key == 1) { g_gemm_variant = value; return 0; }
@@ -569,6 +662,7 @@ extern "C" int dh_set_tuning(int key, int value) {
     if (key == 24) { extern int g_w4_fast_epi; g_w4_fast_epi = value; return 0; }
     if (key == 25) { extern int g_w4_persist_qkv; g_w4_persist_qkv = value != 0; return 0; }
     if (key == 26) { extern int g_tn_mfma; g_tn_mfma = value != 0; return 0; }
+    if (key == 31) { g_skinny_n = value != 0; return 0; }
     if (key == 30) { extern int g_w4_persist_lora; g_w4_persist_lora = value != 0; return 0; }
     if (key == 29) { extern int g_attn_bwd_dkdv_img; g_attn_bwd_dkdv_img = value != 0; return 0; }
     if (key == 28) { extern int g_tail_split; g_tail_split = value != 0; return 0; }

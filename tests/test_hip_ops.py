@@ -738,3 +738,23 @@ def test_noise_mask_classifier(dev):
               f"bit-exact vs ref bf16 {(got == want_b).float().mean().item():.1%}")
         assert e_hip <= 1.5 * e_ref + 1e-3
         assert torch.equal(got.argmax(-1), want_f.argmax(-1)) or (got - want_f).abs().max() < 0.02
+
+
+@pytest.mark.parametrize("M,N,K", [(4480, 48, 2048), (17920, 16, 2048), (1000, 64, 2560), (700, 32, 128)])
+def test_skinny_n_gemm_keeps_the_tiled_kernels_bits(dev, M, N, K):
+    """dh_linear_bf16 with 16-64 output columns and many rows (the LoRA down-projections of the fine-tune, x . A^T of a prefill) runs on
+    gemm_skinny_n_kernel: the bits of the 128-tile kernel (dh_set_tuning(31, 0)) and the oracle's F.linear to one bf16 rounding."""
+    from dualhyp_amd import ops, _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N)
+    x = (torch.randn(M, K, generator=g) * 0.5).bfloat16().to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16().to(dev)
+    got = ops.linear(x, w)
+    try:
+        lib.dh_set_tuning(31, 0)
+        want = ops.linear(x, w)
+    finally:
+        lib.dh_set_tuning(31, 1)
+    assert torch.equal(got, want)
+    ref = (x.float() @ w.float().T)
+    assert (got.float() - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item()
