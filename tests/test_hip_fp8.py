@@ -5,6 +5,9 @@ its distance to the fp32 function must not exceed the oracle fp8 restatement's, 
 reference's."""
 import math
 
+import functools
+import json
+
 import pytest
 import torch
 
@@ -205,6 +208,24 @@ def test_fp8_decoder_vs_oracle_restatement():
     assert all(torch.equal(o.cpu(), alone[i % 2]) for i, o in enumerate(mixed))
 
 
+@functools.lru_cache(maxsize=1)
+def _oracle_fp8(cfg_json, kw_json):
+    """The oracle's fp8 restatement of a synthetic model (quantising ~1 GB of weights on the CPU takes a minute: the two fixtures of
+    test_fp8_llama3_shape_vs_reference share the configuration and the seed, so they share it)."""
+    from dualhyp_amd import Config
+    from dualhyp_amd.synth import synth_state_dict
+    from oracle import ger_oracle as O
+    cfg = Config(**json.loads(cfg_json))
+    # generated on the GPU and copied: the counter-based generator gives the same tensors on both devices (checked once below on a
+    # small tensor), 0.7 s against two minutes on the host cores for the 1.1 G parameters of this shape
+    sd = {k: v.cpu() for k, v in synth_state_dict(cfg, device=DEV, **json.loads(kw_json)).items()}
+    small = Config(**{**json.loads(cfg_json), "n_layer": 1, "padded_vocab_size": 512, "vocab_size": 512, "n_embd": 256, "intermediate_size": 512,
+                      "n_head": 2, "n_query_groups": 1})
+    a, b = synth_state_dict(small, **json.loads(kw_json)), synth_state_dict(small, device=DEV, **json.loads(kw_json))
+    assert all(torch.equal(a[k], b[k].cpu()) for k in a)
+    return O.OracleGPT(cfg, O.quantize_state_dict_fp8(sd, cfg))
+
+
 @pytest.mark.parametrize("name", ["llama3_shape", "llama3_shape_1536"])
 def test_fp8_llama3_shape_vs_reference(golden, name):
     """BASELINE config 5's layer shape (Llama-3-8B: d 4096, hs 128, 8 groups, I 14336, V 128256; 2 layers) in fp8 mode
@@ -229,7 +250,7 @@ def test_fp8_llama3_shape_vs_reference(golden, name):
         lg = m(t["idx"].view(1, -1).to(DEV), torch.arange(T, device=DEV))[0, -4:, :4096].float().cpu()
     m.reset_cache()
     f32, bf = t["prefill_logits_last4_v4096_fp32"].float(), t["prefill_logits_last4_v4096"].float()
-    oq = O.OracleGPT(cfg, O.quantize_state_dict_fp8(synth_state_dict(cfg, **kw), cfg))
+    oq = _oracle_fp8(json.dumps(meta["config"], sort_keys=True), json.dumps(kw, sort_keys=True))
     with torch.no_grad():      # the head on the four compared rows only (activations are quantised per token: rows are independent)
         want_q = oq.lm_head(oq.hidden(t["idx"].view(1, -1), torch.arange(T))[:, -4:])[0, :, :4096].float()
     d_hip, d_orc, d_bf = rel_rms(lg, f32), rel_rms(want_q, f32), rel_rms(bf, f32)
