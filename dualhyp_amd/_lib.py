@@ -55,6 +55,7 @@ SIGNATURES = {
     "dh_dropout_bf16": (I, [P, P, P, I64, F, C.c_uint64, C.c_uint32, P, P]),
     "dh_swiglu_fwd_bf16": (I, [P, P, P, I64, P]),
     "dh_linear_swiglu_train_bf16": (I, [P, P, P, P, P, P, I, I, I, P]),
+    "dh_linear_mul_bf16": (I, [P, P, P, I, I, I, P, P]),
     "dh_swiglu_bwd_bf16": (I, [P, P, P, P, I, I, P]),
     "dh_rmsnorm_bwd_bf16": (I, [P, P, P, P, P, I, I, F, P]),
     "dh_qkv_rope_bwd_bf16": (I, [P, P, P, P, P, P, P, I, I, I, I, P]),

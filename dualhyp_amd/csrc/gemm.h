@@ -19,6 +19,7 @@ struct GemmArgs {
     int nb_n, nb_m;
     int gm;            // m-tiles per band of the 256-tile kernel's block order
     int fast_epi;      // 4-wave kernel: bit 0 the v_dot2_f32_bf16 fused-QKV epilogue, bit 1 the v_dot2 LoRA / residual epilogues (dh_set_tuning(24, bits))
+    int resid_mul;     // 256-tile kernels, PLAIN + resid: the `resid` operand is an elementwise MULTIPLIER, y = bf16(bf16(acc) * resid) (dh_linear_mul_bf16)
     // DH_EPI_QKV (256-tile kernel only): the fused-QKV projection whose epilogue also rotates q / k, writes q and
     // appends k / v to the KV cache (what dh_qkv_rope_cache_bf16 does in a separate pass over the qkv tensor)
     const bf16_t* rope_cos;

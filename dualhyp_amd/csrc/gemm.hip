@@ -361,6 +361,19 @@ extern "C" int dh_linear_swiglu_train_bf16(const dh_bf16* x, const dh_bf16* w1, 
     return dh_swiglu_fwd_bf16(g, u, act, (int64_t)M * I, stream);
 }
 
+// y = bf16(bf16(x . W^T) * mul): a plain GEMM whose epilogue multiplies by an [M, N] bf16 operand where it rounds (round 4, ABI 6) — the
+// dropout mask of a LoRA branch in the fine-tune's backward (d drop(x) / dx = m), otherwise one more elementwise pass over
+// [tokens, d].  The bits of dh_linear_bf16 followed by a bf16 multiply.  256-tile range only (dh_linear_is_big): the caller multiplies
+// small cases itself.
+extern "C" int dh_linear_mul_bf16(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N, int K, const dh_bf16* mul, void* stream) {
+    DH_CHECK(x && w && y && mul, "dh_linear_mul_bf16: null argument");
+    DH_CHECK(M > 0 && N > 0 && K > 0 && K % BK == 0 && N % 8 == 0, "dh_linear_mul_bf16: bad shape M=%d N=%d K=%d", M, N, K);
+    DH_CHECK(M > 32 && dh_linear_is_big(M, N, DH_EPI_PLAIN), "dh_linear_mul_bf16: M=%d N=%d is below the 256-tile kernels' range", M, N);
+    GemmArgs a{};
+    a.x = x; a.w = w; a.y = y; a.resid = mul; a.resid_mul = 1; a.M = M; a.N = N; a.K = K; a.lora_scale = 1.f;
+    return dh_linear_256(a, DH_EPI_PLAIN, (hipStream_t)stream);
+}
+
 int dh_linear_impl(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N, int K, int epilogue,
                    const dh_bf16* w2, const dh_bf16* xa, int xa_ld, const dh_bf16* lora_b, float lora_scale,
                    int split0, int split1, const dh_bf16* vec_a, const dh_bf16* vec_b, const dh_bf16* resid,

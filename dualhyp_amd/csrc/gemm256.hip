@@ -467,9 +467,13 @@ __device__ __forceinline__ void g256_epilogue(const GemmArgs& a, f32x4 (&acc)[8]
                     dot2_sum8_pack(pk, out.x, out.y, out.z, out.w);
                 } else if (RES) {
                     const uint4 rr = rrv[RES ? ip : 0];
-                    auto add2 = [](uint32_t y2, uint32_t r2) __attribute__((always_inline)) -> uint32_t {
-                        return pack2bf(bf2f((bf16_t)(r2 & 0xffffu)) + bf2f((bf16_t)(y2 & 0xffffu)),
-                                       bf2f((bf16_t)(r2 >> 16)) + bf2f((bf16_t)(y2 >> 16)));
+                    // resid_mul (wave-uniform; dh_linear_mul_bf16, 8-wave kernel only): the operand multiplies — the dropout mask of a LoRA branch's
+                    // backward applied where the product is rounded, instead of one more pass over [tokens, d]
+                    const bool mul = a.resid_mul != 0;
+                    auto add2 = [mul](uint32_t y2, uint32_t r2) __attribute__((always_inline)) -> uint32_t {
+                        const float rl = bf2f((bf16_t)(r2 & 0xffffu)), rh = bf2f((bf16_t)(r2 >> 16));
+                        const float yl = bf2f((bf16_t)(y2 & 0xffffu)), yh = bf2f((bf16_t)(y2 >> 16));
+                        return mul ? pack2bf(rl * yl, rh * yh) : pack2bf(rl + yl, rh + yh);
                     };
                     out = make_uint4(add2(out.x, rr.x), add2(out.y, rr.y), add2(out.z, rr.z), add2(out.w, rr.w));
                 }
@@ -479,10 +483,13 @@ __device__ __forceinline__ void g256_epilogue(const GemmArgs& a, f32x4 (&acc)[8]
                 auto with_resid = [&](uint2 t, int n) __attribute__((always_inline)) -> uint2 {
                     if (!RES) return t;
                     const uint2 rr = *reinterpret_cast<const uint2*>(a.resid + (size_t)m * a.N + n);
-                    return make_uint2(pack2bf(bf2f((bf16_t)(rr.x & 0xffffu)) + bf2f((bf16_t)(t.x & 0xffffu)),
-                                              bf2f((bf16_t)(rr.x >> 16)) + bf2f((bf16_t)(t.x >> 16))),
-                                      pack2bf(bf2f((bf16_t)(rr.y & 0xffffu)) + bf2f((bf16_t)(t.y & 0xffffu)),
-                                              bf2f((bf16_t)(rr.y >> 16)) + bf2f((bf16_t)(t.y >> 16))));
+                    const bool mul = a.resid_mul != 0;
+                    auto op = [mul](uint32_t r2, uint32_t y2) __attribute__((always_inline)) -> uint32_t {
+                        const float rl = bf2f((bf16_t)(r2 & 0xffffu)), rh = bf2f((bf16_t)(r2 >> 16));
+                        const float yl = bf2f((bf16_t)(y2 & 0xffffu)), yh = bf2f((bf16_t)(y2 >> 16));
+                        return mul ? pack2bf(rl * yl, rh * yh) : pack2bf(rl + yl, rh + yh);
+                    };
+                    return make_uint2(op(rr.x, t.x), op(rr.y, t.y));
                 };
                 if (m_ok && na < a.N) *reinterpret_cast<uint2*>(a.y + (size_t)m * a.N + na) = with_resid(ta, na);
                 if (m_ok && na + 16 < a.N) *reinterpret_cast<uint2*>(a.y + (size_t)m * a.N + na + 16) = with_resid(tb, na + 16);
@@ -1426,6 +1433,7 @@ int dh_linear_256(GemmArgs a, int epilogue, hipStream_t s) {
     a.fast_epi = g_w4_fast_epi;
     a.nb_m = cdiv(a.M, BT2);
     a.nb_n = (epilogue == DH_EPI_SWIGLU) ? cdiv(a.N, 128) : cdiv(a.N, BT2);
+    if (a.resid_mul) return launch_one<DH_EPI_PLAIN, true, 2>(a, s);      // (checked by dh_linear_mul_bf16: plain epilogue, multiplier present)
     switch (epilogue) {
         case DH_EPI_PLAIN: return launch<DH_EPI_PLAIN>(a, s);
         case DH_EPI_LORA: return launch<DH_EPI_LORA>(a, s);

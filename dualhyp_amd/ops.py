@@ -6,6 +6,7 @@ tensor or a missing library raises.
 """
 from __future__ import annotations
 
+import os
 from typing import Sequence, Optional, Tuple
 
 import torch
@@ -445,6 +446,19 @@ def linear_swiglu_train(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor):
     g, u = torch.empty_like(act), torch.empty_like(act)
     check(_lib.load().dh_linear_swiglu_train_bf16(k(x), k(w1), k(w2), _p(act), _p(g), _p(u), M, I, K, _stream()))
     return act, g, u
+
+
+def linear_mul(x: torch.Tensor, w: torch.Tensor, mul: torch.Tensor) -> torch.Tensor:
+    """bf16(bf16(x @ w.T) * mul): the multiply inside the GEMM's epilogue for large shapes (dh_linear_mul_bf16), else linear then *."""
+    M, K = x.shape
+    N = w.size(0)
+    if (M >= 256 and N >= 256 and -(-M // 256) * -(-N // 256) >= 128 and mul.is_contiguous() and mul.shape == (M, N)
+            and not os.environ.get("DUALHYP_NO_LINEAR_MUL")):        # (the variable: same-box A/B of the fused multiply)
+        k = _Keep()
+        y = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+        check(_lib.load().dh_linear_mul_bf16(k(x), k(w), _p(y), M, N, K, k(mul), _stream()))
+        return y
+    return linear(x, w) * mul
 
 
 def swiglu_bwd(dact: torch.Tensor, g: torch.Tensor, u: torch.Tensor) -> torch.Tensor:

@@ -249,8 +249,8 @@ class _DecoderFn(torch.autograd.Function):
                 if L.mask2 is None:
                     dy = ops.linear(dx1, W["proj_T"], epilogue=ops.EPI_LORA, xa=t, lora_b=ApT, lora_scale=s)
                 else:
-                    lo = ops.linear(_pad64(t), ApT64)
-                    dy = ops.linear(dx1, W["proj_T"], resid=_masked(lo, L.mask2, s))
+                    lo = ops.linear_mul(_pad64(t), ApT64, L.mask2)          # (t Ap) * mask, rounded as the two steps
+                    dy = ops.linear(dx1, W["proj_T"], resid=_masked(lo, None, s))
                 gB2 = torch.empty((d, 16), dtype=torch.float32, device=dev)      # written whole (accumulate=False)
                 gA2 = torch.empty((16, d), dtype=torch.float32, device=dev)
                 ops.tn_accum(dx1, L.xa2, gB2, scale=s, accumulate=False)
@@ -269,8 +269,8 @@ class _DecoderFn(torch.autograd.Function):
                 s0, s1 = qkv_m.splits
                 bounds = (0, s0, s1, qd)
                 t3 = ops.linear(dqkv, Bblk)                              # [n,64], cols 16seg.. = dqkv[:,seg] · B_seg
-                lo = ops.linear(t3, A48T64)                              # [n,d] = t3 · A48
-                dn1 = ops.linear(dqkv, W["qkv_T"], resid=_masked(lo, L.mask1, s))
+                lo = ops.linear(t3, A48T64) if L.mask1 is None else ops.linear_mul(t3, A48T64, L.mask1)      # [n,d] = (t3 · A48) * mask
+                dn1 = ops.linear(dqkv, W["qkv_T"], resid=_masked(lo, None, s))
                 gB1 = torch.empty((qd, 16), dtype=torch.float32, device=dev)    # every segment written whole below
                 if s0 % 128 == 0 and s1 % 128 == 0 and dqkv.size(0) >= 64:
                     ops.tn_accum(dqkv, L.xa, gB1, scale=s, accumulate=False, splits=(s0, s1))      # the three segments in one launch

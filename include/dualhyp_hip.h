@@ -213,6 +213,11 @@ int dh_dropout_bf16(const dh_bf16* x, dh_bf16* y, dh_bf16* mask, int64_t n, floa
                     const uint64_t* step_dev, void* stream);
 /* act = bf16(bf16(silu(g)) * u) from stored g, u (training forward keeps both; ger/model.py:315) */
 int dh_swiglu_fwd_bf16(const dh_bf16* g, const dh_bf16* u, dh_bf16* act, int64_t n, void* stream);
+/* y = bf16(bf16(x . W^T) * mul), mul [M, N] bf16 (round 4, ABI 6): a plain GEMM that applies an elementwise multiplier where it
+ * rounds — the bits of dh_linear_bf16 followed by a bf16 multiply (the LoRA-branch dropout mask in the fine-tune's backward).
+ * Large shapes only: M >= 256, N >= 256, ceil(M/256) * ceil(N/256) >= 128. */
+int dh_linear_mul_bf16(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N, int K,
+                       const dh_bf16* mul, void* stream);
 /* Training forward of fc_1 / fc_2 in one launch (round 4, ABI 6): act = bf16(bf16(silu(g)) * u) with g = bf16(x.W1^T), u = bf16(x.W2^T)
  * also stored ([M, I] each) for the backward — the bits of two dh_linear_bf16 launches + dh_swiglu_fwd_bf16 (ger/model.py:313-315). */
 int dh_linear_swiglu_train_bf16(const dh_bf16* x, const dh_bf16* w1, const dh_bf16* w2, dh_bf16* act,

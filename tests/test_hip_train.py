@@ -767,3 +767,16 @@ def test_segmented_token_contraction_is_the_three_calls(T):
     assert torch.equal(got, want)
     ref = torch.cat([0.5 * a[:, bounds[i]:bounds[i + 1]].float().T @ b[:, 16 * i:16 * i + 16].float() for i in range(3)])
     assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-4
+
+
+@pytest.mark.parametrize("M,N,K", [(17920, 2048, 64), (4200, 2000, 64), (4200, 2048, 256), (300, 512, 64)])
+def test_gemm_with_a_multiplier_in_the_epilogue(M, N, K):
+    """dh_linear_mul_bf16 (the LoRA branch's dropout mask applied where the backward's rank-r product is rounded) against
+    dh_linear_bf16 followed by a bf16 multiply: the same bits — full tiles, ragged rows and a ragged column tile, and the small-shape
+    fallback of ops.linear_mul."""
+    from dualhyp_amd import ops
+    x, w = U((M, K), 1.0, f"lmx{M}").to(DEV), U((N, K), 0.2, f"lmw{N}").to(DEV)
+    keep = (U((M, N), 1.0, f"lmm{M}").float() > -0.9).to(torch.bfloat16).to(DEV)
+    mask = (keep * (1.0 / 0.95)).to(torch.bfloat16)
+    got = ops.linear_mul(x, w, mask)
+    assert torch.equal(got, ops.linear(x, w) * mask)
