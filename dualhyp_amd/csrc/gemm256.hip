@@ -29,7 +29,7 @@
 #include "gemm.h"
 
 int g_w4_fast_epi = 7;  // dh_set_tuning(24, bits): bit 0 the fused-QKV epilogue of full tiles in its v_dot2_f32_bf16 form (g256_epilogue_qkv_fast), bit 1 the same arithmetic in the LoRA / residual epilogues; bit 2: a persistent block's tile start leaves the previous FULL tile's last stores in flight (counted wait); 0 = the round-3 forms (A/B)
-int g_w4_persist_lora = 1;  // dh_set_tuning(30, 0 | 1): persistent blocks for the LoRA GEMM with the in-GEMM down-projection (attn proj of the prefill)
+int g_w4_persist_lora = 1;  // dh_set_tuning(30, 0 | 1): persistent blocks for the LoRA GEMM with the in-GEMM down-projection (attn proj of the prefill) and for plain + residual (mlp proj): the epilogue's hook requests the next tile's stages through the counted builtin
 int g_w4_persist_qkv = 0;   // dh_set_tuning(25, 0 | 1): persistent blocks for the fused-QKV GEMM with the in-GEMM LoRA.  OFF: measured 374-384 us per launch
                             // against 373-374 per-tile (same box, round 4): the tile loop keeps the K loop's invariants live across the epilogue (45 spilled registers)
 int g_w4_persist = 1;   // dh_set_tuning(22, 0 | 1 | 2): the 4-wave kernel walks the tiles with one block per CU: never / where the epilogue loads nothing / always

@@ -291,7 +291,6 @@ __global__ __launch_bounds__(256, 2) void tn_accum_mfma_kernel(const bf16_t* __r
     // ---- DMA sources.  large piece pi of a stage: tokens 4 pi + (lane & 3), 16-byte chunk lane >> 2 of the block's 256 bytes (clamped
     // to the row's last chunk: L % 8 == 0); wave w moves pieces 4 w .. 4 w + 3.  small piece sp: image sp >> 1, tokens 32 (sp & 1) + lane / 2.
     const int colc = min(l0 + 8 * (lane >> 2), L - 8);
-    const int n_sp = 2 * SB;
     auto big_off = [&](int j, int t_stage) __attribute__((always_inline)) -> uint32_t {
         const int t = min(t_stage + 16 * wave + 4 * j + (lane & 3), T - 1);
         return ((uint32_t)t * (uint32_t)ldbig + (uint32_t)colc) * 2u;
@@ -301,7 +300,6 @@ __global__ __launch_bounds__(256, 2) void tn_accum_mfma_kernel(const bf16_t* __r
         const int t = min(t_stage + 32 * (sp & 1) + (lane >> 1), T - 1);
         return ((uint32_t)t * (uint32_t)ldsm + (uint32_t)(s0 + 16 * (sp >> 1) + 8 * (lane & 1))) * 2u;
     };
-    (void)n_sp;
     auto issue = [&](int st) __attribute__((always_inline)) {
         char* base = tn_smem + (st % NST) * STAGE;
         const int t_stage = st * TS;
