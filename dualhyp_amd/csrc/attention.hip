@@ -44,7 +44,9 @@ __global__ __launch_bounds__(HS == 64 ? 1024 : 512) void attn_prefill_kernel(
     //  Nor are they instruction count or phase lock-step, as far as two more experiments go: the subtraction and the log2 e
     //  multiplication of the softmax on packed pairs (24 fewer VALU instructions per step) 207-210 us; S of step kt+1 issued in front
     //  of the softmax of step kt (software pipelining inside the wave, bit-identical, one more S tile: 163 VGPRs = one block per
-    //  CU 284 us, forced to 128 with 17 spills 277 us).)
+    //  CU 284 us, forced to 128 with 17 spills 277 us).  Round 4: all eight K fragments of a step read in one batch in front of the
+    //  eight S MFMAs and the eight V^T fragments in front of the PV MFMAs (sched_barrier; 128 VGPRs, 5 spilled): 200-209 us against 200-203,
+    //  tools/time_attn_prefill.py — the operand reads' LDS latency is not it either.)
     __shared__ __attribute__((aligned(16))) char sKV[2][4 * TILE_B];
 
     const int seq = blockIdx.z, g = blockIdx.y;
