@@ -758,3 +758,27 @@ def test_skinny_n_gemm_keeps_the_tiled_kernels_bits(dev, M, N, K):
     assert torch.equal(got, want)
     ref = (x.float() @ w.float().T)
     assert (got.float() - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("M", [8192, 8115, 700])
+def test_persistent_lora_and_residual_tiles_keep_the_bits(dev, M):
+    """Round 4: the attn-proj (LoRA with the in-GEMM down-projection + residual) and mlp-proj (plain + residual) GEMMs run persistent
+    blocks whose epilogue requests the next tile's first stages (dh_set_tuning(30, 1), the default) and start a tile with a counted
+    wait that leaves the previous tile's last stores in flight (dh_set_tuning(24, bit 2)): bit-equal to one block per tile with
+    vmcnt(0), on full and ragged row counts."""
+    from dualhyp_amd import ops, _lib
+    lib = _lib.load()
+    d, I = 2048, 5632
+    x, act, res = U((M, d), 1.0, f"px{M}").to(dev), U((M, I), 1.0, f"pa{M}").to(dev), U((M, d), 1.0, f"pr{M}").to(dev)
+    Wp, Wm = U((d, d), 0.05, "pwp").to(dev), U((d, I), 0.05, "pwm").to(dev)
+    A16, Bp = U((16, d), 0.05, "pa16").to(dev), U((d, 16), 0.05, "pbp").to(dev)
+    run = lambda: (ops.linear_lora(x, Wp, A16, Bp, lora_scale=2.0, resid=res), ops.linear(act, Wm, resid=res))
+    got = run()
+    try:
+        lib.dh_set_tuning(30, 0)
+        lib.dh_set_tuning(24, 3)
+        want = run()
+    finally:
+        lib.dh_set_tuning(30, 1)
+        lib.dh_set_tuning(24, 7)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
