@@ -372,3 +372,24 @@ def test_feature_files_are_keyed_by_the_corruption_variant():
     ka, kb = D.feature_key(a, "Audio_Corruption", 2), D.feature_key(b, "Audio_Corruption", 2)
     assert ka != kb and ka.startswith("u1.") and kb.startswith("u1.") and ka == D.feature_key(dict(a), "Audio_Corruption", 2)
     assert D.feature_key(a, "Visual_Corruption", 2) == D.feature_key(b, "Visual_Corruption", 2)    # same visual record -> same file
+
+
+def test_attention_backward_plan_is_the_inverse_map():
+    """ops.attn_bwd_plan (host logic of the fine-tune's attention backward, built once per micro-step): every sequence starts at a
+    multiple of 32 in the padded order, pad_tok maps each padded position back to its token (or -1 for padding), and the map is a
+    bijection between tokens and non-padding positions — checked on the CPU, no kernel involved."""
+    import torch
+    from dualhyp_amd import ops
+    lens = [70, 33, 1, 128, 31]
+    n_tok = sum(lens)
+    i32 = torch.int32
+    starts = torch.tensor([sum(lens[:i]) for i in range(len(lens))], dtype=i32)
+    plan = ops.attn_bwd_plan(starts, torch.tensor(lens, dtype=i32), n_tok, lens)
+    assert plan["n_pad"] == sum(-(-n // 32) * 32 for n in lens) and plan["n_seq"] == len(lens)
+    ps, pt = plan["pad_start"].tolist(), plan["pad_tok"].tolist()
+    assert all(p % 32 == 0 for p in ps) and ps == [0, 96, 160, 192, 320]
+    assert sorted(t for t in pt if t >= 0) == list(range(n_tok))
+    for i, n in enumerate(lens):
+        assert pt[ps[i]:ps[i] + n] == list(range(int(starts[i]), int(starts[i]) + n))      # tokens in order, then padding
+        end = ps[i + 1] if i + 1 < len(lens) else plan["n_pad"]
+        assert all(t == -1 for t in pt[ps[i] + n:end])
