@@ -41,6 +41,9 @@ int dh_linear_skinny(const GemmArgs& a, int epilogue, hipStream_t s);
 // y[M, N] = bf16(x . W^T), N = 16 .. 64, thousands of rows (gemm_skinny.hip: gemm_skinny_n_kernel); the bits of the tiled kernels
 bool dh_linear_skinny_n_ok(int M, int N, int K, const void* x, const void* w, const void* y);
 int dh_linear_skinny_n(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N, int K, hipStream_t s);
+// y[M, N] = bf16(x[M, 64] . W^T) [* mul] for a wide N (gemm_skinny.hip: gemm_k64_kernel); the bits of the tiled kernels
+bool dh_linear_k64_ok(int M, int N, int K, const void* x, const void* w, const void* y, const void* mul);
+int dh_linear_k64(const dh_bf16* x, const dh_bf16* w, const dh_bf16* mul, dh_bf16* y, int M, int N, hipStream_t s);
 // the in-GEMM LoRA down-projection can run for these arguments (4-wave 256-tile kernel, tile-aligned segments): gemm256.hip
 bool dh_linear_256_xa_ok(const GemmArgs& a, int epilogue);
 

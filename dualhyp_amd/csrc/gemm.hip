@@ -369,6 +369,7 @@ extern "C" int dh_linear_mul_bf16(const dh_bf16* x, const dh_bf16* w, dh_bf16* y
     DH_CHECK(x && w && y && mul, "dh_linear_mul_bf16: null argument");
     DH_CHECK(M > 0 && N > 0 && K > 0 && K % BK == 0 && N % 8 == 0, "dh_linear_mul_bf16: bad shape M=%d N=%d K=%d", M, N, K);
     DH_CHECK(M > 32 && dh_linear_is_big(M, N, DH_EPI_PLAIN), "dh_linear_mul_bf16: M=%d N=%d is below the 256-tile kernels' range", M, N);
+    if (dh_linear_k64_ok(M, N, K, x, w, y, mul)) return dh_linear_k64(x, w, mul, y, M, N, (hipStream_t)stream);     // rank-padded LoRA product
     GemmArgs a{};
     a.x = x; a.w = w; a.y = y; a.resid = mul; a.resid_mul = 1; a.M = M; a.N = N; a.K = K; a.lora_scale = 1.f;
     return dh_linear_256(a, DH_EPI_PLAIN, (hipStream_t)stream);
@@ -392,6 +393,8 @@ int dh_linear_impl(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, int N,
     if ((kernel == 2 || (kernel == 0 && M <= 32)) && (epilogue != DH_EPI_SWIGLU || (w2 != nullptr && resid == nullptr)) &&
         (epilogue != DH_EPI_ADAPTER || (vec_a && vec_b)) && dh_linear_mid_ok(a, epilogue))
         return dh_linear_mid(a, epilogue, s);
+    if (kernel == 0 && epilogue == DH_EPI_PLAIN && resid == nullptr && dh_linear_k64_ok(M, N, K, x, w, y, nullptr))
+        return dh_linear_k64(x, w, nullptr, y, M, N, s);
     if (kernel == 0 && epilogue == DH_EPI_PLAIN && resid == nullptr && dh_linear_skinny_n_ok(M, N, K, x, w, y))
         return dh_linear_skinny_n(x, w, y, M, N, K, s);          // a LoRA down-projection of a long batch: 16-64 output columns
     const bool skinny = (kernel == 0 || kernel == 2) && M <= 32 && K % 32 == 0;   // weight-streaming kernel (gemm_skinny.hip)

@@ -549,6 +549,75 @@ __global__ __launch_bounds__(256, 2) void gemm_skinny_n_kernel(const bf16_t* __r
     }
 }
 
+// ---------------------------------------------------------------------------------- K = 64 GEMM (round 4)
+// y[M, N] = bf16(x[M, 64] . W[N, 64]^T) (* mul[M, N]): the up-projection of a rank-padded LoRA product in the fine-tune's backward
+// ((dy . B) . A, rank 16 / 48 padded to 64, then the branch's dropout mask).  Two MFMAs per 16 x 16 output tile and 73 MB to write
+// (plus the mask to read): on the 256-tile kernels a tile's fixed cost dominates (52 us per call with the mask, 2.8 TB/s).  Here a block
+// owns 64 rows x 256 columns, x and W land in LDS once (LDS-DMA, whole 128-byte rows, the skinny-N kernel's swizzle), a wave finishes
+// its 16 rows against the 16 column tiles, pairs of tiles regrouped by v_permlane16_swap into 16-byte stores as the 256-tile epilogues do.
+// One accumulator, k ascending: the bits of the tiled kernels; the multiply rounds as a separate bf16 multiply would.
+template <bool MUL>
+__global__ __launch_bounds__(256, 4) void gemm_k64_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                          const bf16_t* __restrict__ mul, bf16_t* __restrict__ y, int M, int N) {
+    constexpr int RB = 64, CB = 256, XB = RB * 128, WB = CB * 128;
+    __shared__ __attribute__((aligned(16))) char k64_smem[XB + WB];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int m0 = blockIdx.y * RB, n0 = blockIdx.x * CB;
+    // pieces of 8 rows x 128 B: x 8 (two per wave), W 32 (eight per wave); position P of row r holds chunk P ^ ((r >> 1) & 7)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = 8 * (2 * wave + i) + (lane >> 3);
+        const int row = min(m0 + r, M - 1);
+        glds16_saddr(x, ((uint32_t)row * 64u + (uint32_t)(((lane & 7) ^ ((r >> 1) & 7)) * 8)) * 2u, k64_smem + (2 * wave + i) * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = 8 * (8 * wave + i) + (lane >> 3);
+        const int row = min(n0 + r, N - 1);
+        glds16_saddr(w, ((uint32_t)row * 64u + (uint32_t)(((lane & 7) ^ ((r >> 1) & 7)) * 8)) * 2u, k64_smem + XB + (8 * wave + i) * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int frow = lane & 15, kg = lane >> 4;
+    const int xr = 16 * wave + frow, m = m0 + xr;
+    bf16x8 bf[2];
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) bf[kh] = *reinterpret_cast<const bf16x8*>(k64_smem + xr * 128 + (((4 * kh + kg) ^ ((xr >> 1) & 7)) << 4));
+    const bool m_ok = m < M;
+    const int cpair = (kg & 1) * 16 + (kg >> 1) * 8;          // this lane's 8 columns inside a 32-column pair after the swap
+#pragma unroll
+    for (int tp = 0; tp < CB / 32; ++tp) {
+        f32x4 acc[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int wr = 32 * tp + 16 * h + frow;
+            acc[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kh = 0; kh < 2; ++kh) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(k64_smem + XB + wr * 128 + (((4 * kh + kg) ^ ((wr >> 1) & 7)) << 4));
+                acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[kh], acc[h], 0, 0, 0);
+            }
+        }
+        // lane (row frow, kg): columns 4 kg .. + 3 of tile h -> after the swaps 8 consecutive columns of the pair
+        const uint2 ta = make_uint2(pack2bf(acc[0][0], acc[0][1]), pack2bf(acc[0][2], acc[0][3]));
+        const uint2 tb = make_uint2(pack2bf(acc[1][0], acc[1][1]), pack2bf(acc[1][2], acc[1][3]));
+        const auto rx = __builtin_amdgcn_permlane16_swap(ta.x, tb.x, false, false);
+        const auto ry = __builtin_amdgcn_permlane16_swap(ta.y, tb.y, false, false);
+        uint4 out = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+        const int n = n0 + 32 * tp + cpair;
+        if (m_ok && n + 8 <= N) {
+            if (MUL) {
+                const uint4 mv = *reinterpret_cast<const uint4*>(mul + (size_t)m * N + n);
+                auto mul2 = [](uint32_t y2, uint32_t r2) __attribute__((always_inline)) -> uint32_t {
+                    return pack2bf(bf2f((bf16_t)(r2 & 0xffffu)) * bf2f((bf16_t)(y2 & 0xffffu)), bf2f((bf16_t)(r2 >> 16)) * bf2f((bf16_t)(y2 >> 16)));
+                };
+                out = make_uint4(mul2(out.x, mv.x), mul2(out.y, mv.y), mul2(out.z, mv.z), mul2(out.w, mv.w));
+            }
+            *reinterpret_cast<uint4*>(y + (size_t)m * N + n) = out;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int dh_linear_partial_bf16(const dh_bf16* x, const dh_bf16* w, const dh_bf16* w_ext, float* y32, int M,
@@ -630,6 +699,19 @@ int dh_linear_skinny_n(const dh_bf16* x, const dh_bf16* w, dh_bf16* y, int M, in
         case 3: hipLaunchKernelGGL((gemm_skinny_n_kernel<3>), grid, block, lds, s, x, w, y, M, K, N); break;
         default: hipLaunchKernelGGL((gemm_skinny_n_kernel<4>), grid, block, lds, s, x, w, y, M, K, N); break;
     }
+    DH_LAUNCH_CHECK();
+    return 0;
+}
+
+// y = bf16(x . W^T) [* mul] for K = 64 and a wide N (gemm_k64_kernel); N % 8 == 0 so that a lane's 8 columns are all inside or all outside
+bool dh_linear_k64_ok(int M, int N, int K, const void* x, const void* w, const void* y, const void* mul) {
+    return g_skinny_n && K == 64 && N >= 256 && N % 8 == 0 && M >= 512 && (size_t)M * 128 < (1ull << 32) && (size_t)N * 128 < (1ull << 32) &&
+           (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)mul) & 15) == 0;
+}
+int dh_linear_k64(const dh_bf16* x, const dh_bf16* w, const dh_bf16* mul, dh_bf16* y, int M, int N, hipStream_t s) {
+    const dim3 grid(cdiv(N, 256), cdiv(M, 64)), block(256);
+    if (mul) hipLaunchKernelGGL((gemm_k64_kernel<true>), grid, block, 0, s, x, w, mul, y, M, N);
+    else hipLaunchKernelGGL((gemm_k64_kernel<false>), grid, block, 0, s, x, w, mul, y, M, N);
     DH_LAUNCH_CHECK();
     return 0;
 }

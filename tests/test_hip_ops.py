@@ -740,10 +740,11 @@ def test_noise_mask_classifier(dev):
         assert torch.equal(got.argmax(-1), want_f.argmax(-1)) or (got - want_f).abs().max() < 0.02
 
 
-@pytest.mark.parametrize("M,N,K", [(4480, 48, 2048), (17920, 16, 2048), (1000, 64, 2560), (700, 32, 128)])
+@pytest.mark.parametrize("M,N,K", [(4480, 48, 2048), (17920, 16, 2048), (1000, 64, 2560), (700, 32, 128), (1000, 520, 64), (4480, 2048, 64)])
 def test_skinny_n_gemm_keeps_the_tiled_kernels_bits(dev, M, N, K):
     """dh_linear_bf16 with 16-64 output columns and many rows (the LoRA down-projections of the fine-tune, x . A^T of a prefill) runs on
-    gemm_skinny_n_kernel: the bits of the 128-tile kernel (dh_set_tuning(31, 0)) and the oracle's F.linear to one bf16 rounding."""
+    gemm_skinny_n_kernel, with K = 64 and a wide N (the rank-padded up-projections) on gemm_k64_kernel: the bits of the tiled kernels
+    (dh_set_tuning(31, 0)) and the oracle's F.linear to one bf16 rounding."""
     from dualhyp_amd import ops, _lib
     lib = _lib.load()
     g = torch.Generator().manual_seed(M + N)

@@ -780,3 +780,12 @@ def test_gemm_with_a_multiplier_in_the_epilogue(M, N, K):
     mask = (keep * (1.0 / 0.95)).to(torch.bfloat16)
     got = ops.linear_mul(x, w, mask)
     assert torch.equal(got, ops.linear(x, w) * mask)
+    # K = 64 runs on gemm_k64_kernel (with and without the multiplier): the bits of the tiled kernels (dh_set_tuning(31, 0))
+    from dualhyp_amd import _lib
+    try:
+        _lib.load().dh_set_tuning(31, 0)
+        want = ops.linear(x, w) * mask
+        want_mul = ops.linear_mul(x, w, mask)
+    finally:
+        _lib.load().dh_set_tuning(31, 1)
+    assert torch.equal(got, want) and torch.equal(got, want_mul)
