@@ -270,6 +270,7 @@ class _DecoderFn(torch.autograd.Function):
         grads: List[Optional[torch.Tensor]] = []
         per_layer: List[List[Optional[torch.Tensor]]] = []
         bwd_plan = ops.attn_bwd_plan(q_start, q_len, B * T, [T] * B)      # one set of index tensors for all layers
+        go = getattr(ctx, "grad_out", None)          # GraphedTrainStep: {id(parameter): fp32 accumulator of its shape}
         for li in range(cfg.n_layer - 1, -1, -1):
             blk, L, W = model.transformer.h[li], ctx.saved[li], fz.layers[li]
             qkv_m, proj_m = blk.attn.attn, blk.attn.proj
@@ -289,10 +290,14 @@ class _DecoderFn(torch.autograd.Function):
                 else:
                     lo = ops.linear_mul(_pad64(t), ApT64, L.mask2)          # (t Ap) * mask, rounded as the two steps
                     dy = ops.linear(dx1, W["proj_T"], resid=_masked(lo, None, s))
-                gB2 = torch.empty((d, 16), dtype=torch.float32, device=dev)      # written whole (accumulate=False)
-                gA2 = torch.empty((16, d), dtype=torch.float32, device=dev)
-                ops.tn_accum(dx1, L.xa2, gB2, scale=s, accumulate=False)
-                ops.tn_accum(t, L.yd, gA2, scale=s, accumulate=False)
+                direct2 = go is not None and proj_m.r == 16 and go[id(proj_m.lora_A)].dtype == torch.float32
+                if direct2:                                                      # straight into the caller's accumulators
+                    gA2, gB2 = go[id(proj_m.lora_A)], go[id(proj_m.lora_B)]
+                else:
+                    gB2 = torch.empty((d, 16), dtype=torch.float32, device=dev)      # written whole (accumulate=False)
+                    gA2 = torch.empty((16, d), dtype=torch.float32, device=dev)
+                ops.tn_accum(dx1, L.xa2, gB2, scale=s, accumulate=direct2)
+                ops.tn_accum(t, L.yd, gA2, scale=s, accumulate=direct2)
             else:
                 dy = ops.linear(dx1, W["proj_T"])
             # ---- attention + rope
@@ -309,27 +314,35 @@ class _DecoderFn(torch.autograd.Function):
                 t3 = ops.linear(dqkv, Bblk)                              # [n,64], cols 16seg.. = dqkv[:,seg] · B_seg
                 lo = ops.linear(t3, A48T64) if L.mask1 is None else ops.linear_mul(t3, A48T64, L.mask1)      # [n,d] = (t3 · A48) * mask
                 dn1 = ops.linear(dqkv, W["qkv_T"], resid=_masked(lo, None, s))
-                gB1 = torch.empty((qd, 16), dtype=torch.float32, device=dev)    # every segment written whole below
+                direct1 = (go is not None and qkv_m.r == 16 and all(qkv_m.enable_lora) and go[id(qkv_m.lora_A)].dtype == torch.float32)
+                if direct1:
+                    gA1, gB1 = go[id(qkv_m.lora_A)], go[id(qkv_m.lora_B)]
+                else:
+                    gB1 = torch.empty((qd, 16), dtype=torch.float32, device=dev)    # every segment written whole below
+                    gA1 = torch.empty((48, d), dtype=torch.float32, device=dev)
                 if s0 % 128 == 0 and s1 % 128 == 0 and dqkv.size(0) >= 64:
-                    ops.tn_accum(dqkv, L.xa, gB1, scale=s, accumulate=False, splits=(s0, s1))      # the three segments in one launch
+                    ops.tn_accum(dqkv, L.xa, gB1, scale=s, accumulate=direct1, splits=(s0, s1))      # the three segments in one launch
                 else:
                     for seg in range(3):
                         ops.tn_accum(dqkv[:, bounds[seg]:bounds[seg + 1]], L.xa[:, 16 * seg:16 * seg + 16],
-                                     gB1[bounds[seg]:bounds[seg + 1]], scale=s, accumulate=False)
-                gA1 = torch.empty((48, d), dtype=torch.float32, device=dev)
-                ops.tn_accum(t3[:, :48], L.n1d, gA1, scale=s, accumulate=False)
+                                     gB1[bounds[seg]:bounds[seg + 1]], scale=s, accumulate=direct1)
+                ops.tn_accum(t3[:, :48], L.n1d, gA1, scale=s, accumulate=direct1)
             else:
                 dn1 = ops.linear(dqkv, W["qkv_T"])
             dx = ops.rmsnorm_bwd(dn1, L.x, blk.norm_1.weight.data, cfg.norm_eps, dres=dx1)
             # ---- map the rank-padded gradients back onto the parameters' shapes
             lg: List[Optional[torch.Tensor]] = []
-            if qkv_m.lora_active:
+            if qkv_m.lora_active and direct1:
+                lg += [None, None]                                           # already in the caller's accumulators
+            elif qkv_m.lora_active:
                 r, en = qkv_m.r, qkv_m.enable_lora
                 lg.append(torch.cat([gA1[16 * seg:16 * seg + r] for seg in range(3) if en[seg]], dim=0))
                 s0, s1 = qkv_m.splits
                 bounds = (0, s0, s1, gB1.size(0))
                 lg.append(torch.cat([gB1[bounds[seg]:bounds[seg + 1], :r] for seg in range(3) if en[seg]], dim=0))
-            if proj_m.lora_active:
+            if proj_m.lora_active and direct2:
+                lg += [None, None]
+            elif proj_m.lora_active:
                 lg += [gA2[:proj_m.r], gB2[:, :proj_m.r]]
             per_layer.append(lg)
             ctx.saved[li] = None                                         # free this layer's activations
@@ -411,11 +424,17 @@ class GraphedTrainStep:
         if not fz.scale_is_one:
             dz = dz * model.lm_head.adapter_scale.data
         dxf = torch.zeros_like(xf).index_copy_(0, rows, ops.linear(dz.contiguous(), fz.lm_T))
-        grads = _DecoderFn.backward(ctx, dxf)[2:]
-        off = 0
-        for p, g in zip(self.params, grads):
-            self.bucket.flat[off:off + p.numel()].add_(g.reshape(-1).to(torch.float32))
+        # the backward accumulates rank-16 all-enabled adapters' gradients straight into the bucket's views (the token contraction's
+        # last step is `out += scale * sum` either way: the same bits as computing them apart and adding), and returns None for those
+        off, views = 0, []
+        for p in self.params:
+            views.append(self.bucket.flat[off:off + p.numel()].view(p.shape))
             off += p.numel()
+        ctx.grad_out = None if os.environ.get("DUALHYP_NO_DIRECT_GRADS") else {id(p): v for p, v in zip(self.params, views)}      # (the variable: same-box A/B)
+        grads = _DecoderFn.backward(ctx, dxf)[2:]
+        for v, g in zip(views, grads):
+            if g is not None:
+                v.add_(g.reshape(v.shape).to(torch.float32))
 
     def _state(self, P: int, T_pad: int, dev, n_rows: int):
         n = P * T_pad
