@@ -259,6 +259,7 @@ def main() -> None:
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    torch.manual_seed(1337 + rank)      # the fine-tune's LoRA-dropout masks are keyed by torch's seed: the same line from run to run
     # under a launcher (WORLD_SIZE set) the process group is created even for ONE rank, so the collectives of the N > 1 path
     # (barrier, MAX all-reduce of the wall time, the fine-tune's flat-bucket all-reduce) run through RCCL on a one-GPU box too
     use_pg = world > 1 or ("WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ)
