@@ -1094,7 +1094,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
     constexpr int OPB = TILE_B;                       // bytes per operand of a stage (256 rows x 128 B)
     constexpr int BUF = 2 * TILE_B + (XA ? 2048 : 0); // bytes per stage (XA: + 16 rows of A)
     constexpr int NP = XA ? 17 : 16;                  // DMA pieces per wave and stage
-    constexpr bool CONT = PERSIST && ((XA && (EPI == DH_EPI_LORA || EPI == DH_EPI_QKV)) || (!XA && EPI == DH_EPI_PLAIN && RESID));   // see the tile loop
+    constexpr bool CONT = PERSIST;                    // every persistent kernel streams its stages across tiles: see the tile loop
     const char* xs_img = smem + 2 * BUF;              // XA: [256][16] bf16, written after the K loop
     // ---- DMA sources: wave w moves row groups R = 8 w .. 8 w + 7 (8 rows x 128 B each) of W and of x
     uint32_t voA[8], voB[8], voX = 0;
@@ -1214,8 +1214,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
     first_stages();
     const int nwg = a.nb_n * a.nb_m;
     // PERSIST: the grid is one block per CU and a block walks tiles bid, bid + grid, ...; the first two stages of the NEXT tile are
-    // requested before the epilogue of the current one, so the epilogue, its store drain, the block dispatch and the first stage's
-    // latency overlap (the tile's K loop is only K / 64 = 32 iterations at K = 2048)
+    // requested by the last two iterations of the current one (CONT below), so the epilogue, its store drain, the block dispatch and
+    // the first stage's latency overlap (the tile's K loop is only K / 64 = 32 iterations at K = 2048)
     bool prev_full = false;
     for (int vb = blockIdx.x, first = 1;; first = 0) {
 #pragma unroll
@@ -1242,6 +1242,21 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
         G256_STAMP_T(vb, 1);
 #pragma unroll
         for (int r = 0; r < NP; ++r) rd(r, 0, 0, fa0, fb0);
+        // The zeroed accumulators must BE in their registers a few cycles before the first asm MFMA reads them: the compiler sees no MFMA
+        // there and may sink a v_accvgpr_write to the instruction in front of it (tools/check_asm_mfma.py found two in the CONT kernels).
+        // Empty volatile asms tie every accumulator in front of an s_nop; volatile asms keep their order.
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (i < 7) asm volatile("" : "+a"(acc[i][j]));
+                else asm volatile("" : "+v"(acc[i][j]));
+            }
+        if constexpr (XA) {
+#pragma unroll
+            for (int jx = 0; jx < 4; ++jx) asm volatile("" : "+v"(xacc[jx]));
+        }
+        asm volatile("s_nop 3" ::: "memory");
         // CONT (the persistent LoRA / residual tiles): the stream of stage requests never drains — the last two iterations of a tile
         // request stages 0 and 1 of the block's NEXT tile into the buffers they free, behind the same MFMAs that hide every other
         // request (34 requests issued from inside the epilogue cost it ~4 us: tools/probe_w4_persistent.py).  The epilogue's own loads
@@ -1250,7 +1265,6 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
         const bool more = PERSIST && vb_next < nwg;
         int m0n = 0, n0n = 0;
         if (more) g256_tile_origin<EPI>(a, vb_next, m0n, n0n);
-        constexpr bool cont = CONT;                  // (the launcher takes a CONT kernel only for an even number of stages)
         int st = 0;
         for (; st + 2 < nst; ++st) iteration(T, T, st, st + 2);
         if constexpr (CONT) {
@@ -1289,22 +1303,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt256w4_kernel(GemmArgs a) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
-        constexpr bool LATE_DMA = false;             // (round 4's first form: requested from inside the epilogue through a hook; replaced by CONT)
-        if (more && !cont) {
-            if constexpr (!LATE_DMA) {
-                __builtin_amdgcn_s_barrier();        // every wave has read its last fragments: both buffers are free
-                setup_src(m0n, n0n);
-                first_stages();
-            }
-        }
-        // (XA kernels: the barrier behind the x.A^T image above already stands between every wave's last fragment read and this point)
-        auto next_tile_dma = [&]() __attribute__((always_inline)) {
-            if constexpr (CONT) return;              // (the K loop's last iterations have requested them)
-            if (more) {
-                setup_src(m0n, n0n);                 // (recomputed behind the epilogue: kept live across its last strips the 17 offsets spill)
-                first_stages();
-            }
-        };
+        // (round 4's first persistent form requested the next tile's stages from inside the epilogue through this hook; CONT replaced it)
+        auto next_tile_dma = []() __attribute__((always_inline)) {};
         G256_STAMP_T(vb, 2);
         const bool full = m0 + BT2 <= a.M && n0 + (EPI == DH_EPI_SWIGLU ? 128 : BT2) <= a.N;
         if constexpr (EPI == DH_EPI_QKV && XA) {
@@ -1384,9 +1384,9 @@ int launch_w4(const GemmArgs& a, hipStream_t s) {
         // (an even number of 64-deep stages: the buffers' parity carries from a tile's last stage to the next tile's first)
         if (a.lora_a != nullptr) return g_w4_persist_lora && (a.K / 64) % 2 == 0 ? launch_w4p<EPI, RESID, true, true>(a, s) : launch_w4p<EPI, RESID, false, true>(a, s);
     }
-    const bool cont_ok = (a.K / 64) % 2 == 0;       // plain + residual persistent blocks stream their stages across tiles (CONT)
+    const bool cont_ok = (a.K / 64) % 2 == 0;       // persistent blocks stream their stages across tiles (CONT): an even number of stages
     const bool persist = (g_w4_persist == 2 || (g_w4_persist == 1 && ((!RESID && EPI == DH_EPI_PLAIN) || EPI == DH_EPI_SWIGLU)) ||
-                          (g_w4_persist_lora && RESID && EPI == DH_EPI_PLAIN)) && (!(RESID && EPI == DH_EPI_PLAIN) || cont_ok);
+                          (g_w4_persist_lora && RESID && EPI == DH_EPI_PLAIN)) && cont_ok;
     return persist ? launch_w4p<EPI, RESID, true>(a, s) : launch_w4p<EPI, RESID, false>(a, s);
 }
 
