@@ -25,6 +25,8 @@ def stamps(n):
     return out[:n]
 lib.dh_set_tuning(1, int(os.environ.get("G256_VARIANT", "5")))      # 1: 8-wave ping-pong, 5: 4-wave full-line
 lib.dh_set_tuning(22, 0)     # per-tile launches: a block = a tile
+lib.dh_set_tuning(25, 0)     # ... for the fused-QKV kernel
+lib.dh_set_tuning(30, 0)     # ... and the LoRA / residual kernels (tools/probe_w4_persistent.py has the persistent blocks' per-tile timeline)
 H, G, hs, S = 32, 4, 64, 512
 Wq, Wp = rn(2560, d), rn(d, d)
 xa48, xa16, Bq, Bp = rn(M, 48), rn(M, 16), rn(2560, 16), rn(d, 16)
