@@ -1386,7 +1386,7 @@ int launch_w4(const GemmArgs& a, hipStream_t s) {
     }
     const bool cont_ok = (a.K / 64) % 2 == 0;       // persistent blocks stream their stages across tiles (CONT): an even number of stages
     const bool persist = (g_w4_persist == 2 || (g_w4_persist == 1 && ((!RESID && EPI == DH_EPI_PLAIN) || EPI == DH_EPI_SWIGLU)) ||
-                          (g_w4_persist_lora && RESID && EPI == DH_EPI_PLAIN)) && cont_ok;
+                          (g_w4_persist_lora && ((RESID && EPI == DH_EPI_PLAIN) || EPI == DH_EPI_LORA))) && cont_ok;      // (LoRA here: xa from memory, the fine-tune)
     return persist ? launch_w4p<EPI, RESID, true>(a, s) : launch_w4p<EPI, RESID, false>(a, s);
 }
 
